@@ -1,0 +1,293 @@
+/*
+ * parasail_amd.h -- C ABI of libparasail_amd.so, the MI355X (gfx950) engine behind the
+ * parasail-rs `Aligner::align()` hot path.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) The `parasail_*` symbols that parasail-rs binds through libparasail-sys
+ *      (reference file:line given per declaration).  Same names, same argument order and
+ *      meaning, same ownership and error convention (NULL = failure; alignment functions
+ *      never return NULL), so the Rust L2 layer links against this library unchanged
+ *      (INTEGRATION.md).  Every alignment call runs its DP fill on the GPU; there is no
+ *      CPU fallback -- if no HIP device is usable the call aborts with a message on stderr.
+ *
+ *  (2) Additive `pmx_*` batch entry points (no reference counterpart: the reference is
+ *      one pair per call, src/aligner/mod.rs:397).  They take many pairs in packed
+ *      buffers and are what BASELINE.json's throughput configs are measured on.
+ *
+ * Plain C types only; no torch / HIP types in any signature (streams are passed as void*).
+ */
+#ifndef PARASAIL_AMD_H
+#define PARASAIL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ types ---- */
+
+/* Layout read directly by Rust: .type_ (src/matrix/mod.rs:193), .size (:228,:257),
+ * .length (:256), .matrix (:258).  [EXTERNAL] field order follows upstream parasail.h. */
+typedef struct parasail_matrix {
+    const char *name;
+    const int *matrix;      /* length x size, row-major */
+    const int *mapper;      /* 256 entries: byte -> column index */
+    int size;               /* alphabet size incl. the wildcard column */
+    int max;
+    int min;
+    int *user_matrix;       /* non-NULL for matrices owned by the caller (set_value allowed) */
+    int type;               /* 0 = square, 1 = PSSM */
+    int length;             /* rows: == size for square, query length for PSSM */
+    const char *alphabet;
+    const char *query;      /* PSSM only */
+} parasail_matrix_t;
+
+#define PARASAIL_MATRIX_TYPE_SQUARE 0
+#define PARASAIL_MATRIX_TYPE_PSSM   1
+
+/* Opaque to Rust (only passed back): src/alignment/mod.rs:55-60, src/profile/mod.rs:281-285 */
+typedef struct parasail_result parasail_result_t;
+typedef struct parasail_profile parasail_profile_t;
+typedef parasail_profile_t parasail_profile;   /* bindgen alias used at src/profile/mod.rs:115 */
+typedef parasail_matrix_t parasail_matrix;
+
+/* src/alignment/mod.rs:368-374 reads .query/.comp/.ref_; each is a malloc'd C string that
+ * Rust adopts with CString::from_raw. */
+typedef struct parasail_traceback {
+    char *query;
+    char *comp;
+    char *ref;
+} parasail_traceback_t;
+
+typedef struct parasail_cigar {
+    uint32_t *seq;          /* BAM encoding: len << 4 | op, op index into "MIDNSHP=X" */
+    int len;
+    int beg_query;
+    int beg_ref;
+} parasail_cigar_t;
+
+/* src/alignment/mod.rs:513-543 */
+typedef struct parasail_result_ssw {
+    uint16_t score1;
+    int32_t ref_begin1;
+    int32_t ref_end1;
+    int32_t read_begin1;
+    int32_t read_end1;
+    uint32_t *cigar;
+    int32_t cigarLen;
+} parasail_result_ssw_t;
+
+/* trace-table flag values: src/alignment/table.rs:127-142 */
+#define PARASAIL_ZERO_MASK 120
+#define PARASAIL_E_MASK    103
+#define PARASAIL_F_MASK     31
+#define PARASAIL_ZERO   0
+#define PARASAIL_INS    1
+#define PARASAIL_DEL    2
+#define PARASAIL_DIAG   4
+#define PARASAIL_DIAG_E 8
+#define PARASAIL_INS_E  16
+#define PARASAIL_DIAG_F 32
+#define PARASAIL_DEL_F  64
+
+typedef parasail_result_t *parasail_function_t(const char *s1, const int s1Len,
+                                               const char *s2, const int s2Len,
+                                               const int open, const int gap,
+                                               const parasail_matrix_t *matrix);
+typedef parasail_result_t *parasail_pfunction_t(const parasail_profile_t *profile,
+                                                const char *s2, const int s2Len,
+                                                const int open, const int gap);
+typedef parasail_profile_t *parasail_pcreator_t(const char *s1, const int s1Len,
+                                                const parasail_matrix_t *matrix);
+
+/* --------------------------------------------------------------- dispatch ---- */
+/* src/aligner/mod.rs:345 / :349 -- name grammar src/aligner/mod.rs:319-329:
+ *   {nw|sg[_q{b,e,x}][_d{b,e,x}]|sw}[_trace][_stats][_table|_rowcol]_{striped|scan|diag}[_profile]_{sat|8|16|32|64}
+ * A name with or without the leading "parasail_" is accepted.  Unknown name -> NULL. */
+parasail_function_t  *parasail_lookup_function(const char *funcname);
+parasail_pfunction_t *parasail_lookup_pfunction(const char *funcname);
+
+/* src/aligner/mod.rs:470-481 */
+parasail_result_t *parasail_nw_banded(const char *s1, const int s1Len, const char *s2, const int s2Len,
+                                      const int open, const int gap, const int k,
+                                      const parasail_matrix_t *matrix);
+/* src/aligner/mod.rs:500-510, src/profile/mod.rs:345 */
+parasail_result_ssw_t *parasail_ssw(const char *s1, const int s1Len, const char *s2, const int s2Len,
+                                    const int open, const int gap, const parasail_matrix_t *matrix);
+parasail_profile_t *parasail_ssw_init(const char *s1, const int s1Len,
+                                      const parasail_matrix_t *matrix, const int8_t score_size);
+void parasail_result_ssw_free(parasail_result_ssw_t *result);
+
+/* ------------------------------------------------------------------ result --- */
+/* src/alignment/mod.rs:64-98 */
+int parasail_result_get_score(const parasail_result_t *result);
+int parasail_result_get_end_query(const parasail_result_t *result);
+int parasail_result_get_end_ref(const parasail_result_t *result);
+int parasail_result_get_matches(const parasail_result_t *result);
+int parasail_result_get_similar(const parasail_result_t *result);
+int parasail_result_get_length(const parasail_result_t *result);
+/* src/alignment/mod.rs:123-192: [query_len][ref_len] int32 row-major, valid until result_free */
+int *parasail_result_get_score_table(const parasail_result_t *result);
+int *parasail_result_get_matches_table(const parasail_result_t *result);
+int *parasail_result_get_similar_table(const parasail_result_t *result);
+int *parasail_result_get_length_table(const parasail_result_t *result);
+/* src/alignment/mod.rs:195-288: rows have ref_len entries, cols have query_len entries */
+int *parasail_result_get_score_row(const parasail_result_t *result);
+int *parasail_result_get_matches_row(const parasail_result_t *result);
+int *parasail_result_get_similar_row(const parasail_result_t *result);
+int *parasail_result_get_length_row(const parasail_result_t *result);
+int *parasail_result_get_score_col(const parasail_result_t *result);
+int *parasail_result_get_matches_col(const parasail_result_t *result);
+int *parasail_result_get_similar_col(const parasail_result_t *result);
+int *parasail_result_get_length_col(const parasail_result_t *result);
+/* src/alignment/mod.rs:291-307: [query_len][ref_len] one byte per cell */
+int *parasail_result_get_trace_table(const parasail_result_t *result);
+/* src/alignment/mod.rs:356-366, :400-410, :324-339 */
+parasail_traceback_t *parasail_result_get_traceback(parasail_result_t *result,
+        const char *seqA, int lena, const char *seqB, int lenb,
+        const parasail_matrix_t *matrix, char match, char pos, char neg);
+void parasail_traceback_free(parasail_traceback_t *traceback);
+void parasail_traceback_generic(const char *seqA, int lena, const char *seqB, int lenb,
+        const char *nameA, const char *nameB, const parasail_matrix_t *matrix,
+        parasail_result_t *result, char match, char pos, char neg,
+        int width, int name_width, int use_stats);
+parasail_cigar_t *parasail_result_get_cigar(parasail_result_t *result,
+        const char *seqA, int lena, const char *seqB, int lenb, const parasail_matrix_t *matrix);
+char *parasail_cigar_decode(parasail_cigar_t *cigar);      /* malloc'd, caller frees */
+void parasail_cigar_free(parasail_cigar_t *cigar);
+/* src/alignment/mod.rs:422-494 */
+int parasail_result_is_nw(const parasail_result_t *result);
+int parasail_result_is_sg(const parasail_result_t *result);
+int parasail_result_is_sw(const parasail_result_t *result);
+int parasail_result_is_saturated(const parasail_result_t *result);
+int parasail_result_is_banded(const parasail_result_t *result);
+int parasail_result_is_scan(const parasail_result_t *result);
+int parasail_result_is_striped(const parasail_result_t *result);
+int parasail_result_is_diag(const parasail_result_t *result);
+int parasail_result_is_blocked(const parasail_result_t *result);
+int parasail_result_is_stats(const parasail_result_t *result);
+int parasail_result_is_stats_table(const parasail_result_t *result);
+int parasail_result_is_table(const parasail_result_t *result);
+int parasail_result_is_rowcol(const parasail_result_t *result);
+int parasail_result_is_stats_rowcol(const parasail_result_t *result);
+int parasail_result_is_trace(const parasail_result_t *result);
+/* src/alignment/mod.rs:498-504 */
+void parasail_result_free(parasail_result_t *result);
+
+/* ------------------------------------------------------------------ matrix --- */
+/* src/matrix/mod.rs:40, :62, :140, :158, :188-197, :238, :281, :304 */
+parasail_matrix_t *parasail_matrix_create(const char *alphabet, const int match, const int mismatch);
+const parasail_matrix_t *parasail_matrix_lookup(const char *matrixname);
+parasail_matrix_t *parasail_matrix_from_file(const char *filename);
+parasail_matrix_t *parasail_matrix_pssm_create(const char *alphabet, const int *values, const int length);
+parasail_matrix_t *parasail_matrix_convert_square_to_pssm(const parasail_matrix_t *matrix,
+                                                          const char *s1, int s1Len);
+parasail_matrix_t *parasail_matrix_copy(const parasail_matrix_t *matrix);
+void parasail_matrix_set_value(parasail_matrix_t *matrix, int row, int col, int value);
+void parasail_matrix_free(parasail_matrix_t *matrix);
+
+/* ----------------------------------------------------------------- profile --- */
+/* src/profile/mod.rs:113-277 picks one of these by (stats, ISA, width); on the GPU the ISA
+ * slot is meaningless, so all ISA-suffixed names are aliases of the generic ones. */
+#define PMX_DECLARE_PROFILE_CREATORS(ISA) \
+    parasail_profile_t *parasail_profile_create##ISA##_sat(const char *, const int, const parasail_matrix_t *); \
+    parasail_profile_t *parasail_profile_create##ISA##_8(const char *, const int, const parasail_matrix_t *);   \
+    parasail_profile_t *parasail_profile_create##ISA##_16(const char *, const int, const parasail_matrix_t *);  \
+    parasail_profile_t *parasail_profile_create##ISA##_32(const char *, const int, const parasail_matrix_t *);  \
+    parasail_profile_t *parasail_profile_create##ISA##_64(const char *, const int, const parasail_matrix_t *);  \
+    parasail_profile_t *parasail_profile_create_stats##ISA##_sat(const char *, const int, const parasail_matrix_t *); \
+    parasail_profile_t *parasail_profile_create_stats##ISA##_8(const char *, const int, const parasail_matrix_t *);   \
+    parasail_profile_t *parasail_profile_create_stats##ISA##_16(const char *, const int, const parasail_matrix_t *);  \
+    parasail_profile_t *parasail_profile_create_stats##ISA##_32(const char *, const int, const parasail_matrix_t *);  \
+    parasail_profile_t *parasail_profile_create_stats##ISA##_64(const char *, const int, const parasail_matrix_t *);
+PMX_DECLARE_PROFILE_CREATORS()
+PMX_DECLARE_PROFILE_CREATORS(_sse_128)
+PMX_DECLARE_PROFILE_CREATORS(_avx_256)
+PMX_DECLARE_PROFILE_CREATORS(_neon_128)
+PMX_DECLARE_PROFILE_CREATORS(_altivec_128)
+/* src/profile/mod.rs:384-390 */
+void parasail_profile_free(parasail_profile_t *profile);
+
+/* ------------------------------------------------- additive batch interface --- */
+
+#define PMX_MODE_NW 0
+#define PMX_MODE_SG 1
+#define PMX_MODE_SW 2
+/* semi-global free ends: q = query (s1), d = reference (s2) */
+#define PMX_SG_QB 1
+#define PMX_SG_QE 2
+#define PMX_SG_DB 4
+#define PMX_SG_DE 8
+#define PMX_SG_ALL 15
+
+#define PMX_WANT_STATS 1     /* matches / similar / length per pair */
+#define PMX_WANT_CIGAR 2     /* on-device traceback, CIGAR text per pair */
+
+#define PMX_FLAG_SATURATED 1 /* result record flag: the requested width overflowed */
+
+typedef struct pmx_config {
+    int mode;                /* PMX_MODE_* */
+    int sg_flags;            /* PMX_SG_* (ignored unless mode == SG) */
+    int open;                /* positive; a gap of length k costs open + (k-1)*extend */
+    int extend;
+    int width;               /* 0 = sat (promote on overflow), 8, 16, 32, 64 */
+    int want;                /* PMX_WANT_* */
+    const parasail_matrix_t *matrix;
+} pmx_config_t;
+
+/* One record per pair, 16 bytes. */
+typedef struct pmx_record {
+    int32_t score;
+    int32_t end_query;       /* 0-based inclusive */
+    int32_t end_ref;
+    int32_t flags;           /* PMX_FLAG_* */
+} pmx_record_t;
+
+typedef struct pmx_stats {
+    int32_t matches, similar, length;
+} pmx_stats_t;
+
+/* Sequences are packed back to back: pair k's query is qbuf[qoff[k] .. qoff[k+1]).
+ * Returns 0 on success, <0 on error (pmx_last_error() describes it). */
+
+/* Host buffers in, host records out (H2D + kernels + D2H inside). */
+int pmx_align_batch(const pmx_config_t *cfg, int64_t n,
+                    const uint8_t *qbuf, const int64_t *qoff,
+                    const uint8_t *rbuf, const int64_t *roff,
+                    pmx_record_t *out, pmx_stats_t *stats_out /* NULL unless WANT_STATS */);
+
+/* Device-resident buffers (all pointers are device pointers on the current device),
+ * asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream). */
+int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
+                           const uint8_t *d_qbuf, const int64_t *d_qoff,
+                           const uint8_t *d_rbuf, const int64_t *d_roff,
+                           int32_t max_qlen, int32_t max_rlen,
+                           pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream);
+
+/* One reused query profile against many references (profile arm, src/aligner/mod.rs:431-450). */
+int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,
+                            const uint8_t *rbuf, const int64_t *roff,
+                            pmx_record_t *out, pmx_stats_t *stats_out);
+
+/* CIGAR text for a batch (semi-global / global / local with traceback done on the device).
+ * cigar_off has n+1 entries; *cigar_buf is malloc'd by the callee and freed with pmx_free. */
+int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
+                          const uint8_t *qbuf, const int64_t *qoff,
+                          const uint8_t *rbuf, const int64_t *roff,
+                          pmx_record_t *out, char **cigar_buf, int64_t *cigar_off);
+void pmx_free(void *p);
+
+/* Runtime. */
+int pmx_device_count(void);
+int pmx_set_device(int device);            /* per calling thread, like hipSetDevice */
+const char *pmx_last_error(void);
+const char *pmx_version(void);
+/* Name of the kernel family the dispatcher would use for a config and size (diagnostics). */
+const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen, int32_t max_rlen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARASAIL_AMD_H */

@@ -1,0 +1,221 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package never does.  See oracle/pmx_oracle.c for what
+is restated and how it is pinned.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libpmx_oracle.so")
+
+NW, SG, SW = 0, 1, 2
+S1_BEG, S1_END, S2_BEG, S2_END = 1, 2, 4, 8
+SG_ALL = S1_BEG | S1_END | S2_BEG | S2_END
+
+
+class _Result(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("score", "end_query", "end_ref", "matches", "similar", "length", "saturated")]
+
+
+class _Outputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("score_table", "matches_table", "similar_table", "length_table",
+                 "score_row", "matches_row", "similar_row", "length_row",
+                 "score_col", "matches_col", "similar_col", "length_col",
+                 "trace_table")]
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("pmx_oracle.c", "pmx_striped_cpu.c", "Makefile")]
+    if (not force and os.path.exists(_SO)
+            and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
+        return _SO
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_align.restype = C.c_int
+        _lib.orc_walk.restype = C.c_int
+        _lib.orc_align_batch.restype = C.c_int
+        _lib.pmx_cpu_sw_striped16_batch.restype = C.c_int
+    return _lib
+
+
+class Matrix:
+    """size x size int32 scores + 256-entry mapper (byte -> row/col index)."""
+
+    def __init__(self, scores, mapper, alphabet=""):
+        self.scores = np.ascontiguousarray(scores, dtype=np.int32)
+        self.size = int(self.scores.shape[0])
+        self.mapper = np.ascontiguousarray(mapper, dtype=np.int32)
+        self.alphabet = alphabet
+
+    @classmethod
+    def create(cls, alphabet, match, mismatch):
+        if isinstance(alphabet, bytes):
+            alphabet = alphabet.decode()
+        n = len(alphabet) + 1
+        m = np.zeros((n, n), dtype=np.int32)
+        mp = np.zeros(256, dtype=np.int32)
+        lib().orc_matrix_create(alphabet.encode(), int(match), int(mismatch),
+                                m.ctypes.data_as(C.c_void_p), mp.ctypes.data_as(C.c_void_p))
+        return cls(m, mp, alphabet)
+
+    @classmethod
+    def default(cls):
+        return cls.create("ACGTA", 1, -1)     # src/matrix/mod.rs:246-250
+
+    @classmethod
+    def from_file(cls, path):
+        """Square-matrix file format of tests/square.txt (comment lines '#', header row of
+        symbols, one row per symbol with a leading repeat of the symbol)."""
+        rows, alphabet = [], None
+        with open(path) as fh:
+            for line in fh:
+                line = line.strip()
+                if not line or line.startswith("#"):
+                    continue
+                tok = line.split()
+                if alphabet is None:
+                    alphabet = tok
+                    continue
+                rows.append([int(x) for x in tok[1:]])
+        n = len(alphabet)
+        m = np.array(rows, dtype=np.int32).reshape(n, n)
+        mp = np.full(256, n - 1, dtype=np.int32)
+        for i, ch in enumerate(alphabet[:-1]):
+            mp[ord(ch.upper())] = i
+            mp[ord(ch.lower())] = i
+        mp[ord(alphabet[-1])] = n - 1
+        return cls(m, mp, "".join(alphabet))
+
+
+class Result:
+    pass
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def align(mode, query, ref, open_, ext, matrix, sg_flags=SG_ALL, bits=0,
+          stats=False, table=False, rowcol=False, trace=False):
+    """One pair through the scalar oracle.  Returns an object with score, end_query,
+    end_ref, saturated and (if requested) stats / tables / rows / cols / trace."""
+    q = np.frombuffer(bytes(query), dtype=np.uint8)
+    r = np.frombuffer(bytes(ref), dtype=np.uint8)
+    ql, rl = len(q), len(r)
+    res, out = _Result(), _Outputs()
+    keep = {}
+
+    def mk(name, shape, dtype=np.int32):
+        a = np.zeros(shape, dtype=dtype)
+        keep[name] = a
+        setattr(out, name, a.ctypes.data)
+
+    if table:
+        mk("score_table", (ql, rl))
+        if stats:
+            for n in ("matches_table", "similar_table", "length_table"):
+                mk(n, (ql, rl))
+    if rowcol:
+        mk("score_row", (rl,)); mk("score_col", (ql,))
+        if stats:
+            for n in ("matches", "similar", "length"):
+                mk(n + "_row", (rl,)); mk(n + "_col", (ql,))
+    if trace:
+        mk("trace_table", (ql, rl), np.int8)
+    rc = lib().orc_align(mode, sg_flags, _ptr(q), ql, _ptr(r), rl, int(open_), int(ext),
+                         _ptr(matrix.scores), matrix.size, _ptr(matrix.mapper),
+                         int(bits), int(stats), C.byref(res), C.byref(out))
+    if rc:
+        raise RuntimeError("orc_align failed rc=%d" % rc)
+    o = Result()
+    for n, _ in _Result._fields_:
+        setattr(o, n, getattr(res, n))
+    for n, a in keep.items():
+        setattr(o, n, a)
+    o.mode, o.query, o.ref, o.matrix = mode, bytes(query), bytes(ref), matrix
+    return o
+
+
+def walk(res):
+    """Traceback walk -> (ops string, beg_query, beg_ref)."""
+    q = np.frombuffer(res.query, dtype=np.uint8)
+    r = np.frombuffer(res.ref, dtype=np.uint8)
+    buf = C.create_string_buffer(len(q) + len(r) + 2)
+    bq, br = C.c_int(), C.c_int()
+    n = lib().orc_walk(res.mode, _ptr(res.trace_table), _ptr(q), len(q), _ptr(r), len(r),
+                       _ptr(res.matrix.mapper), res.end_query, res.end_ref, buf,
+                       C.byref(bq), C.byref(br))
+    if n < 0:
+        raise RuntimeError("orc_walk failed")
+    return buf.value.decode(), bq.value, br.value
+
+
+def cigar(res):
+    ops, _, _ = walk(res)
+    out = C.create_string_buffer(12 * (len(ops) + 1))
+    lib().orc_cigar_text(ops.encode(), len(ops), out, len(out))
+    return out.value.decode()
+
+
+def traceback_strings(res, match="|", pos=" ", neg=" "):
+    ops, bq, br = walk(res)
+    q = np.frombuffer(res.query, dtype=np.uint8)
+    r = np.frombuffer(res.ref, dtype=np.uint8)
+    n = len(ops)
+    qs, cs, rs = (C.create_string_buffer(n + 1) for _ in range(3))
+    lib().orc_traceback_strings(ops.encode(), n, _ptr(q), _ptr(r), bq, br,
+                                _ptr(res.matrix.scores), res.matrix.size, _ptr(res.matrix.mapper),
+                                C.c_char(match.encode()), C.c_char(pos.encode()), C.c_char(neg.encode()),
+                                qs, cs, rs)
+    return qs.value.decode(), cs.value.decode(), rs.value.decode()
+
+
+def pack(seqs):
+    """list of bytes -> (uint8 buffer, int64 offsets[n+1])."""
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    np.cumsum([len(s) for s in seqs], out=off[1:])
+    buf = np.frombuffer(b"".join(bytes(s) for s in seqs), dtype=np.uint8).copy()
+    return buf, off
+
+
+def align_batch(mode, qbuf, qoff, rbuf, roff, open_, ext, matrix, sg_flags=SG_ALL, bits=0):
+    n = len(qoff) - 1
+    out = np.zeros((n, 3), dtype=np.int32)
+    qoff = np.ascontiguousarray(qoff, dtype=np.int64)
+    roff = np.ascontiguousarray(roff, dtype=np.int64)
+    rc = lib().orc_align_batch(mode, sg_flags, C.c_long(n), _ptr(qbuf), _ptr(qoff), _ptr(rbuf), _ptr(roff),
+                               int(open_), int(ext), _ptr(matrix.scores), matrix.size, _ptr(matrix.mapper),
+                               int(bits), _ptr(out))
+    if rc:
+        raise RuntimeError("orc_align_batch: some pair failed")
+    return out
+
+
+def cpu_sw_striped16_batch(qbuf, qoff, rbuf, roff, open_, ext, matrix, threads=0):
+    """CPU timing baseline (Farrar striped int16, AVX2 + OpenMP).  Returns (out[n,3], threads_used)."""
+    n = len(qoff) - 1
+    out = np.zeros((n, 3), dtype=np.int32)
+    qoff = np.ascontiguousarray(qoff, dtype=np.int64)
+    roff = np.ascontiguousarray(roff, dtype=np.int64)
+    used = lib().pmx_cpu_sw_striped16_batch(C.c_long(n), _ptr(qbuf), _ptr(qoff), _ptr(rbuf), _ptr(roff),
+                                            int(open_), int(ext), _ptr(matrix.scores), matrix.size,
+                                            _ptr(matrix.mapper), _ptr(out), int(threads))
+    return out, used

@@ -1,0 +1,1074 @@
+// pmx_api.hip -- the C ABI of libparasail_amd.so (declared in include/parasail_amd.h).
+//
+// Host side of the drop-in boundary: the `parasail_*` symbols parasail-rs binds through
+// libparasail-sys (/root/reference/src/aligner/mod.rs:4-7, src/alignment/mod.rs:6-23,
+// src/matrix/mod.rs:7-11, src/profile/mod.rs:5-32) plus the additive `pmx_*` batch entries.
+// All DP arithmetic is done by the HIP kernels (pmx_sw16.hip, pmx_general.hip); this file
+// owns handles, dispatch-name parsing, device staging and result marshalling only.
+#include "pmx_common.h"
+#include "pmx_matrices.h"
+
+#include <cctype>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+// ============================================================================ errors ====
+static thread_local char g_err[512] = "";
+static void set_err(const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+}
+extern "C" const char *pmx_last_error(void) { return g_err; }
+extern "C" const char *pmx_version(void) { return "parasail_amd 0.1.0 (gfx950)"; }
+
+// The product path has no CPU fallback: a failing HIP call in a function whose signature
+// cannot report errors (the reference never checks alignment results for NULL,
+// src/aligner/mod.rs:411-429) is fatal and loud.
+[[noreturn]] static void die(const char *what, hipError_t e)
+{
+    fprintf(stderr, "libparasail_amd: fatal: %s: %s (no CPU fallback exists)\n", what,
+            e == hipSuccess ? "" : hipGetErrorString(e));
+    abort();
+}
+#define HIP_OR_DIE(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) die(#expr, e__); } while (0)
+#define HIP_OR_RET(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { \
+    set_err("%s: %s", #expr, hipGetErrorString(e__)); return -(int)e__; } } while (0)
+
+extern "C" int pmx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" int pmx_set_device(int device)
+{
+    HIP_OR_RET(hipSetDevice(device));
+    return 0;
+}
+
+// =========================================================================== matrices ===
+struct MatrixBox {               // owns everything a non-builtin parasail_matrix_t points to
+    parasail_matrix_t m;
+    std::vector<int> scores, mapper;
+    std::string name, alphabet, query;
+};
+
+static void finish_box(MatrixBox *b, int type, int length, int size, bool user)
+{
+    b->m.name = b->name.c_str();
+    b->m.matrix = b->scores.data();
+    b->m.mapper = b->mapper.data();
+    b->m.size = size;
+    int mx = INT32_MIN, mn = INT32_MAX;
+    for (int v : b->scores) { mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+    b->m.max = mx; b->m.min = mn;
+    b->m.user_matrix = user ? b->scores.data() : nullptr;
+    b->m.type = type;
+    b->m.length = length;
+    b->m.alphabet = b->alphabet.c_str();
+    b->m.query = b->query.empty() ? nullptr : b->query.c_str();
+}
+
+static std::mutex g_mx_mutex;
+static std::unordered_map<const parasail_matrix_t *, MatrixBox *> g_boxes;   // live non-builtin matrices
+
+static parasail_matrix_t *publish(MatrixBox *b)
+{
+    std::lock_guard<std::mutex> lk(g_mx_mutex);
+    g_boxes[&b->m] = b;
+    return &b->m;
+}
+
+static void fill_mapper(std::vector<int> &mapper, const std::string &alphabet, int wildcard)
+{
+    mapper.assign(256, wildcard);
+    for (size_t i = 0; i < alphabet.size(); ++i) {
+        const unsigned char c = (unsigned char)alphabet[i];
+        mapper[(unsigned char)toupper(c)] = (int)i;
+        mapper[(unsigned char)tolower(c)] = (int)i;
+    }
+}
+
+// src/matrix/mod.rs:34-44.  size = alphabet + 1 wildcard row/col (bound size-2 at :228-236);
+// wildcard scores 0; a repeated letter ("ACGTA", :248) maps to its last position.
+extern "C" parasail_matrix_t *parasail_matrix_create(const char *alphabet, const int match, const int mismatch)
+{
+    if (!alphabet || !*alphabet) return nullptr;
+    MatrixBox *b = new MatrixBox;
+    b->alphabet = std::string(alphabet) + "*";
+    b->name = "";
+    const int n = (int)strlen(alphabet), size = n + 1;
+    b->scores.assign((size_t)size * size, 0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) b->scores[(size_t)i * size + j] = (i == j) ? match : mismatch;
+    fill_mapper(b->mapper, alphabet, n);
+    finish_box(b, PARASAIL_MATRIX_TYPE_SQUARE, size, size, true);
+    return publish(b);
+}
+
+static parasail_matrix_t g_blosum62;
+static std::vector<int> g_blosum62_mapper;
+static std::once_flag g_builtin_once;
+static void init_builtins()
+{
+    fill_mapper(g_blosum62_mapper, std::string(pmx_blosum62_alphabet, 23), 23);
+    g_blosum62_mapper[(unsigned char)'*'] = 23;
+    g_blosum62.name = "blosum62";
+    g_blosum62.matrix = pmx_blosum62_scores;
+    g_blosum62.mapper = g_blosum62_mapper.data();
+    g_blosum62.size = 24; g_blosum62.max = 11; g_blosum62.min = -4;
+    g_blosum62.user_matrix = nullptr; g_blosum62.type = PARASAIL_MATRIX_TYPE_SQUARE;
+    g_blosum62.length = 24; g_blosum62.alphabet = pmx_blosum62_alphabet; g_blosum62.query = nullptr;
+}
+
+// src/matrix/mod.rs:57-73: NULL -> Error::FailedLookup.  Built-ins are static, never freed.
+extern "C" const parasail_matrix_t *parasail_matrix_lookup(const char *matrixname)
+{
+    if (!matrixname) return nullptr;
+    std::call_once(g_builtin_once, init_builtins);
+    std::string s(matrixname);
+    for (auto &c : s) c = (char)tolower((unsigned char)c);
+    if (s == "blosum62") return &g_blosum62;
+    return nullptr;
+}
+
+// File formats: tests/square.txt:1-27 (square, trailing wildcard row/col) and
+// tests/pssm.txt:1-17 (PSSM, optional leading residue column).
+extern "C" parasail_matrix_t *parasail_matrix_from_file(const char *filename)
+{
+    if (!filename) return nullptr;
+    FILE *fh = fopen(filename, "r");
+    if (!fh) return nullptr;
+    std::vector<std::string> header;
+    std::vector<std::vector<std::string>> rows;
+    char line[8192];
+    while (fgets(line, sizeof line, fh)) {
+        char *p = line;
+        while (*p && isspace((unsigned char)*p)) ++p;
+        if (!*p || *p == '#') continue;
+        std::vector<std::string> tok;
+        char *save = nullptr;
+        for (char *t = strtok_r(p, " \t\r\n", &save); t; t = strtok_r(nullptr, " \t\r\n", &save)) tok.emplace_back(t);
+        if (tok.empty()) continue;
+        if (header.empty()) header = tok; else rows.push_back(tok);
+    }
+    fclose(fh);
+    const int n = (int)header.size();
+    if (n < 2 || rows.empty()) return nullptr;
+    for (auto &h : header) if (h.size() != 1) return nullptr;
+    bool square = (int)rows.size() == n;
+    if (square) for (int i = 0; i < n; ++i)
+        if ((int)rows[i].size() != n + 1 || rows[i][0] != header[i]) { square = false; break; }
+    MatrixBox *b = new MatrixBox;
+    b->name = filename;
+    for (auto &h : header) b->alphabet += h;
+    auto parse = [](const std::string &s, int *out) {
+        char *end = nullptr; long v = strtol(s.c_str(), &end, 10);
+        if (!end || *end) return false; *out = (int)v; return true;
+    };
+    if (square) {
+        b->scores.resize((size_t)n * n);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j)
+            if (!parse(rows[i][j + 1], &b->scores[(size_t)i * n + j])) { delete b; return nullptr; }
+        fill_mapper(b->mapper, b->alphabet.substr(0, n - 1), n - 1);
+        b->mapper[(unsigned char)b->alphabet[n - 1]] = n - 1;
+        finish_box(b, PARASAIL_MATRIX_TYPE_SQUARE, n, n, true);
+    } else {
+        const int len = (int)rows.size(), size = n + 1;
+        b->scores.assign((size_t)len * size, 0);
+        for (int i = 0; i < len; ++i) {
+            const int skip = (int)rows[i].size() == n + 1 ? 1 : 0;
+            if ((int)rows[i].size() != n + skip) { delete b; return nullptr; }
+            int mn = INT32_MAX;
+            for (int j = 0; j < n; ++j) {
+                int v; if (!parse(rows[i][j + skip], &v)) { delete b; return nullptr; }
+                b->scores[(size_t)i * size + j] = v; mn = v < mn ? v : mn;
+            }
+            b->scores[(size_t)i * size + n] = mn;
+            if (skip) b->query += rows[i][0];
+        }
+        b->alphabet += "*";
+        fill_mapper(b->mapper, b->alphabet.substr(0, n), n);
+        finish_box(b, PARASAIL_MATRIX_TYPE_PSSM, len, size, true);
+    }
+    return publish(b);
+}
+
+// src/matrix/mod.rs:154-169: `values` holds length * strlen(alphabet) scores, row-major.
+extern "C" parasail_matrix_t *parasail_matrix_pssm_create(const char *alphabet, const int *values, const int length)
+{
+    if (!alphabet || !*alphabet || !values || length <= 0) return nullptr;
+    const int n = (int)strlen(alphabet), size = n + 1;
+    MatrixBox *b = new MatrixBox;
+    b->alphabet = std::string(alphabet) + "*";
+    b->scores.assign((size_t)length * size, 0);
+    for (int i = 0; i < length; ++i) {
+        int mn = INT32_MAX;
+        for (int j = 0; j < n; ++j) { const int v = values[(size_t)i * n + j]; b->scores[(size_t)i * size + j] = v; mn = v < mn ? v : mn; }
+        b->scores[(size_t)i * size + n] = mn;
+    }
+    fill_mapper(b->mapper, alphabet, n);
+    finish_box(b, PARASAIL_MATRIX_TYPE_PSSM, length, size, true);
+    return publish(b);
+}
+
+// src/matrix/mod.rs:180-212
+extern "C" parasail_matrix_t *parasail_matrix_convert_square_to_pssm(const parasail_matrix_t *matrix,
+                                                                   const char *s1, int s1Len)
+{
+    if (!matrix || matrix->type != PARASAIL_MATRIX_TYPE_SQUARE || !s1 || s1Len <= 0) return nullptr;
+    MatrixBox *b = new MatrixBox;
+    b->name = matrix->name ? matrix->name : "";
+    b->alphabet = matrix->alphabet ? matrix->alphabet : "";
+    b->query.assign(s1, (size_t)s1Len);
+    const int size = matrix->size;
+    b->scores.resize((size_t)s1Len * size);
+    for (int i = 0; i < s1Len; ++i)
+        memcpy(&b->scores[(size_t)i * size], &matrix->matrix[(size_t)matrix->mapper[(unsigned char)s1[i]] * size],
+               sizeof(int) * (size_t)size);
+    b->mapper.assign(matrix->mapper, matrix->mapper + 256);
+    finish_box(b, PARASAIL_MATRIX_TYPE_PSSM, s1Len, size, true);
+    return publish(b);
+}
+
+// src/matrix/mod.rs:279-294
+extern "C" parasail_matrix_t *parasail_matrix_copy(const parasail_matrix_t *matrix)
+{
+    if (!matrix) return nullptr;
+    MatrixBox *b = new MatrixBox;
+    b->name = matrix->name ? matrix->name : "";
+    b->alphabet = matrix->alphabet ? matrix->alphabet : "";
+    if (matrix->query) b->query = matrix->query;
+    b->scores.assign(matrix->matrix, matrix->matrix + (size_t)matrix->length * matrix->size);
+    b->mapper.assign(matrix->mapper, matrix->mapper + 256);
+    finish_box(b, matrix->type, matrix->length, matrix->size, true);
+    return publish(b);
+}
+
+static void devcache_drop(const parasail_matrix_t *m);
+
+// src/matrix/mod.rs:222-242 (Rust checks the index range and the builtin flag first)
+extern "C" void parasail_matrix_set_value(parasail_matrix_t *matrix, int row, int col, int value)
+{
+    if (!matrix || !matrix->user_matrix) return;
+    if (row < 0 || col < 0 || row >= matrix->length || col >= matrix->size) return;
+    matrix->user_matrix[(size_t)row * matrix->size + col] = value;
+    if (value > matrix->max) matrix->max = value;
+    if (value < matrix->min) matrix->min = value;
+    devcache_drop(matrix);
+}
+
+// src/matrix/mod.rs:297-307
+extern "C" void parasail_matrix_free(parasail_matrix_t *matrix)
+{
+    if (!matrix) return;
+    MatrixBox *b = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mx_mutex);
+        auto it = g_boxes.find(matrix);
+        if (it == g_boxes.end()) return;       // builtin or unknown: never freed
+        b = it->second; g_boxes.erase(it);
+    }
+    devcache_drop(matrix);
+    delete b;
+}
+
+// ===================================================================== device matrices ===
+struct DevMat { PmxDevMatrix d; int16_t *scores; uint8_t *mapper; uint64_t hash; int rows; };
+static std::mutex g_dev_mutex;
+static std::unordered_map<uint64_t, DevMat> g_devmats;     // key = matrix ptr ^ device
+
+static uint64_t mat_hash(const parasail_matrix_t *m)
+{
+    uint64_t h = 1469598103934665603ULL;
+    auto mix = [&](int v) { h ^= (uint32_t)v; h *= 1099511628211ULL; };
+    const size_t cells = (size_t)m->length * m->size;
+    for (size_t i = 0; i < cells; ++i) mix(m->matrix[i]);
+    for (int i = 0; i < 256; ++i) mix(m->mapper[i]);
+    mix(m->size); mix(m->length); mix(m->type);
+    return h;
+}
+
+static void devcache_drop(const parasail_matrix_t *m)
+{
+    std::lock_guard<std::mutex> lk(g_dev_mutex);
+    for (auto it = g_devmats.begin(); it != g_devmats.end();) {
+        if ((it->first >> 8) == ((uint64_t)(uintptr_t)m)) {
+            (void)hipFree(it->second.scores); (void)hipFree(it->second.mapper);
+            it = g_devmats.erase(it);
+        } else ++it;
+    }
+}
+
+// Upload (once per matrix content and device) the int16 score table + byte mapper.
+static int get_devmat(const parasail_matrix_t *m, DevMat *out)
+{
+    if (!m || !m->matrix || !m->mapper || m->size <= 0 || m->size > 255) { set_err("bad matrix"); return -1; }
+    if (m->max > 32767 || m->min < -32768) { set_err("matrix scores do not fit int16"); return -1; }
+    int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
+    const uint64_t key = ((uint64_t)(uintptr_t)m << 8) | (uint64_t)(dev & 0xFF);
+    const uint64_t h = mat_hash(m);
+    std::lock_guard<std::mutex> lk(g_dev_mutex);
+    auto it = g_devmats.find(key);
+    if (it != g_devmats.end() && it->second.hash == h) { *out = it->second; return 0; }
+    if (it != g_devmats.end()) { (void)hipFree(it->second.scores); (void)hipFree(it->second.mapper); g_devmats.erase(it); }
+    const size_t cells = (size_t)m->length * m->size;
+    std::vector<int16_t> s16(cells); std::vector<uint8_t> map8(256);
+    for (size_t i = 0; i < cells; ++i) s16[i] = (int16_t)m->matrix[i];
+    for (int i = 0; i < 256; ++i) {
+        int v = m->mapper[i];
+        if (v < 0 || v >= m->size) v = m->size - 1;
+        map8[i] = (uint8_t)v;
+    }
+    DevMat dm; dm.hash = h; dm.rows = m->length;
+    HIP_OR_RET(hipMalloc(&dm.scores, cells * 2));
+    HIP_OR_RET(hipMalloc(&dm.mapper, 256));
+    HIP_OR_RET(hipMemcpy(dm.scores, s16.data(), cells * 2, hipMemcpyHostToDevice));
+    HIP_OR_RET(hipMemcpy(dm.mapper, map8.data(), 256, hipMemcpyHostToDevice));
+    dm.d.scores = dm.scores; dm.d.mapper = dm.mapper; dm.d.msize = m->size; dm.d.min = m->min; dm.d.max = m->max;
+    g_devmats[key] = dm;
+    *out = dm;
+    return 0;
+}
+
+// ============================================================================ results ====
+enum {
+    F_NW = 1 << 0, F_SG = 1 << 1, F_SW = 1 << 2, F_SATURATED = 1 << 6, F_BANDED = 1 << 7,
+    F_SCAN = 1 << 10, F_STRIPED = 1 << 11, F_DIAG = 1 << 12, F_BLOCKED = 1 << 13,
+    F_STATS = 1 << 16, F_TABLE = 1 << 17, F_ROWCOL = 1 << 18, F_TRACE = 1 << 19,
+    F_BITS_8 = 1 << 20, F_BITS_16 = 1 << 21, F_BITS_32 = 1 << 22, F_BITS_64 = 1 << 23
+};
+
+struct parasail_result {
+    int score, end_query, end_ref, flag;
+    int matches, similar, length;
+    int qlen, rlen;
+    int *tables[4];        // score, matches, similar, length  [qlen*rlen]
+    int *rows[4];          // [rlen]
+    int *cols[4];          // [qlen]
+    int8_t *trace;         // [qlen*rlen]
+};
+
+extern "C" {
+int parasail_result_get_score(const parasail_result_t *r) { return r->score; }
+int parasail_result_get_end_query(const parasail_result_t *r) { return r->end_query; }
+int parasail_result_get_end_ref(const parasail_result_t *r) { return r->end_ref; }
+int parasail_result_get_matches(const parasail_result_t *r) { return r->matches; }
+int parasail_result_get_similar(const parasail_result_t *r) { return r->similar; }
+int parasail_result_get_length(const parasail_result_t *r) { return r->length; }
+int *parasail_result_get_score_table(const parasail_result_t *r) { return r->tables[0]; }
+int *parasail_result_get_matches_table(const parasail_result_t *r) { return r->tables[1]; }
+int *parasail_result_get_similar_table(const parasail_result_t *r) { return r->tables[2]; }
+int *parasail_result_get_length_table(const parasail_result_t *r) { return r->tables[3]; }
+int *parasail_result_get_score_row(const parasail_result_t *r) { return r->rows[0]; }
+int *parasail_result_get_matches_row(const parasail_result_t *r) { return r->rows[1]; }
+int *parasail_result_get_similar_row(const parasail_result_t *r) { return r->rows[2]; }
+int *parasail_result_get_length_row(const parasail_result_t *r) { return r->rows[3]; }
+int *parasail_result_get_score_col(const parasail_result_t *r) { return r->cols[0]; }
+int *parasail_result_get_matches_col(const parasail_result_t *r) { return r->cols[1]; }
+int *parasail_result_get_similar_col(const parasail_result_t *r) { return r->cols[2]; }
+int *parasail_result_get_length_col(const parasail_result_t *r) { return r->cols[3]; }
+int *parasail_result_get_trace_table(const parasail_result_t *r) { return reinterpret_cast<int *>(r->trace); }
+int parasail_result_is_nw(const parasail_result_t *r) { return !!(r->flag & F_NW); }
+int parasail_result_is_sg(const parasail_result_t *r) { return !!(r->flag & F_SG); }
+int parasail_result_is_sw(const parasail_result_t *r) { return !!(r->flag & F_SW); }
+int parasail_result_is_saturated(const parasail_result_t *r) { return !!(r->flag & F_SATURATED); }
+int parasail_result_is_banded(const parasail_result_t *r) { return !!(r->flag & F_BANDED); }
+int parasail_result_is_scan(const parasail_result_t *r) { return !!(r->flag & F_SCAN); }
+int parasail_result_is_striped(const parasail_result_t *r) { return !!(r->flag & F_STRIPED); }
+int parasail_result_is_diag(const parasail_result_t *r) { return !!(r->flag & F_DIAG); }
+int parasail_result_is_blocked(const parasail_result_t *r) { return !!(r->flag & F_BLOCKED); }
+int parasail_result_is_stats(const parasail_result_t *r) { return !!(r->flag & F_STATS); }
+/* tests/test_parasail.rs:276-279, :397-399: stats+table -> is_table && is_stats && is_stats_table */
+int parasail_result_is_stats_table(const parasail_result_t *r) { return (r->flag & F_STATS) && (r->flag & F_TABLE); }
+int parasail_result_is_table(const parasail_result_t *r) { return !!(r->flag & F_TABLE); }
+int parasail_result_is_rowcol(const parasail_result_t *r) { return !!(r->flag & F_ROWCOL); }
+int parasail_result_is_stats_rowcol(const parasail_result_t *r) { return (r->flag & F_STATS) && (r->flag & F_ROWCOL); }
+int parasail_result_is_trace(const parasail_result_t *r) { return !!(r->flag & F_TRACE); }
+
+void parasail_result_free(parasail_result_t *r)
+{
+    if (!r) return;
+    for (int k = 0; k < 4; ++k) { free(r->tables[k]); free(r->rows[k]); free(r->cols[k]); }
+    free(r->trace);
+    free(r);
+}
+}  // extern "C"
+
+// ====================================================================== single-pair run ===
+struct RunSpec {
+    int mode, sg_flags, band;
+    int width;             // 0 sat, 8, 16, 32, 64
+    bool stats, table, rowcol, trace;
+    int vecflag;           // F_STRIPED / F_SCAN / F_DIAG / 0
+};
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void alloc(size_t n) { HIP_OR_DIE(hipMalloc(&p, (n ? n : 1) * sizeof(T))); }
+};
+
+static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Len, const char *s2, int s2Len,
+                                     int open, int gap, const parasail_matrix_t *matrix)
+{
+    parasail_result_t *res = (parasail_result_t *)calloc(1, sizeof(parasail_result_t));
+    if (!res) die("calloc", hipSuccess);
+    res->qlen = s1Len; res->rlen = s2Len;
+    int flag = sp.vecflag;
+    flag |= sp.mode == PMX_MODE_NW ? F_NW : sp.mode == PMX_MODE_SG ? F_SG : F_SW;
+    if (sp.band >= 0) flag |= F_BANDED;
+    if (sp.stats) flag |= F_STATS;
+    if (sp.table) flag |= F_TABLE;
+    if (sp.rowcol) flag |= F_ROWCOL;
+    if (sp.trace) flag |= F_TRACE;
+    flag |= sp.width == 8 ? F_BITS_8 : sp.width == 16 ? F_BITS_16 : sp.width == 64 ? F_BITS_64 : F_BITS_32;
+    res->flag = flag;
+    if (!s1 || !s2 || s1Len <= 0 || s2Len <= 0 || !matrix) return res;   // degenerate: empty result, never NULL
+
+    DevMat dm;
+    if (get_devmat(matrix, &dm)) die(g_err, hipSuccess);
+    const bool pssm = matrix->type == PARASAIL_MATRIX_TYPE_PSSM;
+    if (pssm && matrix->length != s1Len) die("PSSM length differs from the query length", hipSuccess);
+
+    const size_t cells = (size_t)s1Len * s2Len;
+    DevBuf<uint8_t> dq, dr; DevBuf<int64_t> doff; DevBuf<pmx_record_t> drec; DevBuf<pmx_stats_t> dst;
+    DevBuf<int32_t> dbound, dtab[4], drow[4], dcol[4]; DevBuf<int8_t> dtrace;
+    dq.alloc(s1Len); dr.alloc(s2Len); doff.alloc(4); drec.alloc(1); dst.alloc(1);
+    dbound.alloc((size_t)8 * s2Len);
+    const int64_t offs[4] = {0, s1Len, 0, s2Len};
+    HIP_OR_DIE(hipMemcpy(dq.p, s1, s1Len, hipMemcpyHostToDevice));
+    HIP_OR_DIE(hipMemcpy(dr.p, s2, s2Len, hipMemcpyHostToDevice));
+    HIP_OR_DIE(hipMemcpy(doff.p, offs, sizeof offs, hipMemcpyHostToDevice));
+
+    PmxGeneralArgs a; memset(&a, 0, sizeof a);
+    a.qbuf = dq.p; a.qoff = doff.p; a.rbuf = dr.p; a.roff = doff.p + 2; a.n = 1;
+    a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize;
+    a.mat_rows = matrix->length; a.pssm = pssm ? 1 : 0;
+    a.mode = sp.mode; a.sg_flags = sp.sg_flags; a.open = open; a.ext = gap; a.band = sp.band;
+    a.bits = sp.width;
+    a.bound = dbound.p; a.bound_stride = (long long)8 * s2Len;
+    a.rec = drec.p; a.stats = dst.p;
+    const int ntab = sp.stats ? 4 : 1;
+    if (sp.table) for (int k = 0; k < ntab; ++k) dtab[k].alloc(cells);
+    if (sp.rowcol) for (int k = 0; k < ntab; ++k) { drow[k].alloc(s2Len); dcol[k].alloc(s1Len); }
+    if (sp.trace) dtrace.alloc(cells);
+    a.score_table = dtab[0].p; a.matches_table = dtab[1].p; a.similar_table = dtab[2].p; a.length_table = dtab[3].p;
+    a.score_row = drow[0].p; a.matches_row = drow[1].p; a.similar_row = drow[2].p; a.length_row = drow[3].p;
+    a.score_col = dcol[0].p; a.matches_col = dcol[1].p; a.similar_col = dcol[2].p; a.length_col = dcol[3].p;
+    a.trace_table = dtrace.p;
+
+    int rc = pmx_launch_general(a, sp.stats, nullptr);
+    if (rc) die("general kernel launch failed (matrix too large for LDS?)", hipSuccess);
+    pmx_record_t rec; pmx_stats_t st = {0, 0, 0};
+    HIP_OR_DIE(hipMemcpy(&rec, drec.p, sizeof rec, hipMemcpyDeviceToHost));
+    if (sp.stats) HIP_OR_DIE(hipMemcpy(&st, dst.p, sizeof st, hipMemcpyDeviceToHost));
+    res->score = rec.score; res->end_query = rec.end_query; res->end_ref = rec.end_ref;
+    if (rec.flags & PMX_FLAG_SATURATED) res->flag |= F_SATURATED;
+    res->matches = st.matches; res->similar = st.similar; res->length = st.length;
+    auto fetch = [&](int32_t *d, size_t n) -> int * {
+        if (!d) return nullptr;
+        int *h = (int *)malloc(n * sizeof(int));
+        if (!h) die("malloc", hipSuccess);
+        HIP_OR_DIE(hipMemcpy(h, d, n * sizeof(int), hipMemcpyDeviceToHost));
+        return h;
+    };
+    for (int k = 0; k < 4; ++k) {
+        res->tables[k] = fetch(dtab[k].p, cells);
+        res->rows[k] = fetch(drow[k].p, s2Len);
+        res->cols[k] = fetch(dcol[k].p, s1Len);
+    }
+    if (sp.trace) {
+        res->trace = (int8_t *)malloc(cells);
+        if (!res->trace) die("malloc", hipSuccess);
+        HIP_OR_DIE(hipMemcpy(res->trace, dtrace.p, cells, hipMemcpyDeviceToHost));
+    }
+    return res;
+}
+
+// ============================================================== dispatch-name grammar ====
+// {mode}{sg_gaps}{trace}{stats}{table}{vec}{profile}_{width}     src/aligner/mod.rs:319-329
+// id = ((mode*7 + out)*3 + vec)*5 + width
+//   mode : 0 nw, 1 sw, 2 + q*4 + d  (q,d in {none,b,e,x}) for sg
+//   out  : 0 -, 1 table, 2 rowcol, 3 stats, 4 stats_table, 5 stats_rowcol, 6 trace
+//   vec  : 0 striped, 1 scan, 2 diag          width: 0 sat, 1 8, 2 16, 3 32, 4 64
+static const int N_MODE = 18, N_OUT = 7, N_VEC = 3, N_WIDTH = 5;
+static const int N_IDS = N_MODE * N_OUT * N_VEC * N_WIDTH;
+
+static RunSpec spec_from_id(int id)
+{
+    RunSpec sp; memset(&sp, 0, sizeof sp);
+    const int w = id % N_WIDTH; id /= N_WIDTH;
+    const int v = id % N_VEC; id /= N_VEC;
+    const int o = id % N_OUT; id /= N_OUT;
+    const int m = id;
+    static const int widths[5] = {0, 8, 16, 32, 64};
+    sp.width = widths[w];
+    sp.vecflag = v == 0 ? F_STRIPED : v == 1 ? F_SCAN : F_DIAG;
+    sp.table = (o == 1 || o == 4); sp.rowcol = (o == 2 || o == 5);
+    sp.stats = (o >= 3 && o <= 5); sp.trace = (o == 6);
+    sp.band = -1;
+    if (m == 0) sp.mode = PMX_MODE_NW;
+    else if (m == 1) sp.mode = PMX_MODE_SW;
+    else {
+        sp.mode = PMX_MODE_SG;
+        const int qi = (m - 2) / 4, di = (m - 2) % 4;
+        int f = 0;
+        if (qi == 1 || qi == 3) f |= PMX_SG_QB;
+        if (qi == 2 || qi == 3) f |= PMX_SG_QE;
+        if (di == 1 || di == 3) f |= PMX_SG_DB;
+        if (di == 2 || di == 3) f |= PMX_SG_DE;
+        if (qi == 0 && di == 0) f = PMX_SG_ALL;      // plain "sg": every end free
+        sp.sg_flags = f;
+    }
+    return sp;
+}
+
+static bool eat(const char *&p, const char *tok)
+{
+    const size_t n = strlen(tok);
+    if (strncmp(p, tok, n) == 0) { p += n; return true; }
+    return false;
+}
+
+// returns id or -1; *is_profile reports the _profile slot
+static int parse_name(const char *name, bool *is_profile)
+{
+    if (!name) return -1;
+    const char *p = name;
+    eat(p, "parasail_");
+    int m;
+    if (eat(p, "nw")) m = 0;
+    else if (eat(p, "sw")) m = 1;
+    else if (eat(p, "sg")) {
+        int qi = 0, di = 0;
+        if (eat(p, "_qb")) qi = 1; else if (eat(p, "_qe")) qi = 2; else if (eat(p, "_qx")) qi = 3;
+        if (eat(p, "_db")) di = 1; else if (eat(p, "_de")) di = 2; else if (eat(p, "_dx")) di = 3;
+        m = 2 + qi * 4 + di;
+    } else return -1;
+    const bool trace = eat(p, "_trace");
+    const bool stats = eat(p, "_stats");
+    const bool table = eat(p, "_table");
+    const bool rowcol = !table && eat(p, "_rowcol");
+    if (trace && (stats || table || rowcol)) return -1;
+    int o = trace ? 6 : stats ? (table ? 4 : rowcol ? 5 : 3) : (table ? 1 : rowcol ? 2 : 0);
+    int v;
+    if (eat(p, "_striped")) v = 0; else if (eat(p, "_scan")) v = 1; else if (eat(p, "_diag")) v = 2; else return -1;
+    *is_profile = eat(p, "_profile");
+    if (*is_profile && v == 2) return -1;
+    int w;
+    if (!strcmp(p, "_sat")) w = 0; else if (!strcmp(p, "_8")) w = 1; else if (!strcmp(p, "_16")) w = 2;
+    else if (!strcmp(p, "_32")) w = 3; else if (!strcmp(p, "_64")) w = 4; else return -1;
+    return ((m * N_OUT + o) * N_VEC + v) * N_WIDTH + w;
+}
+
+// ---- profiles --------------------------------------------------------------------------
+struct parasail_profile {
+    char *s1; int s1Len;
+    const parasail_matrix_t *matrix;
+    int stats; int width;
+};
+
+static parasail_profile_t *profile_new(const char *s1, int s1Len, const parasail_matrix_t *matrix, int stats, int width)
+{
+    if (!s1 || s1Len <= 0 || !matrix) return nullptr;       // -> Error::NullProfile (src/profile/mod.rs:101-103)
+    parasail_profile_t *p = (parasail_profile_t *)calloc(1, sizeof *p);
+    if (!p) return nullptr;
+    p->s1 = (char *)malloc((size_t)s1Len + 1);
+    if (!p->s1) { free(p); return nullptr; }
+    memcpy(p->s1, s1, (size_t)s1Len); p->s1[s1Len] = 0;
+    p->s1Len = s1Len; p->matrix = matrix; p->stats = stats; p->width = width;
+    return p;
+}
+extern "C" void parasail_profile_free(parasail_profile_t *p) { if (p) { free(p->s1); free(p); } }
+
+#define PMX_DEFINE_PROFILE_CREATORS(ISA)                                                                    \
+    extern "C" parasail_profile_t *parasail_profile_create##ISA##_sat(const char *s, const int n, const parasail_matrix_t *m) { return profile_new(s, n, m, 0, 0); }  \
+    extern "C" parasail_profile_t *parasail_profile_create##ISA##_8(const char *s, const int n, const parasail_matrix_t *m) { return profile_new(s, n, m, 0, 8); }    \
+    extern "C" parasail_profile_t *parasail_profile_create##ISA##_16(const char *s, const int n, const parasail_matrix_t *m) { return profile_new(s, n, m, 0, 16); }  \
+    extern "C" parasail_profile_t *parasail_profile_create##ISA##_32(const char *s, const int n, const parasail_matrix_t *m) { return profile_new(s, n, m, 0, 32); }  \
+    extern "C" parasail_profile_t *parasail_profile_create##ISA##_64(const char *s, const int n, const parasail_matrix_t *m) { return profile_new(s, n, m, 0, 64); }  \
+    extern "C" parasail_profile_t *parasail_profile_create_stats##ISA##_sat(const char *s, const int n, const parasail_matrix_t *m) { return profile_new(s, n, m, 1, 0); }  \
+    extern "C" parasail_profile_t *parasail_profile_create_stats##ISA##_8(const char *s, const int n, const parasail_matrix_t *m) { return profile_new(s, n, m, 1, 8); }    \
+    extern "C" parasail_profile_t *parasail_profile_create_stats##ISA##_16(const char *s, const int n, const parasail_matrix_t *m) { return profile_new(s, n, m, 1, 16); }  \
+    extern "C" parasail_profile_t *parasail_profile_create_stats##ISA##_32(const char *s, const int n, const parasail_matrix_t *m) { return profile_new(s, n, m, 1, 32); }  \
+    extern "C" parasail_profile_t *parasail_profile_create_stats##ISA##_64(const char *s, const int n, const parasail_matrix_t *m) { return profile_new(s, n, m, 1, 64); }
+PMX_DEFINE_PROFILE_CREATORS()
+PMX_DEFINE_PROFILE_CREATORS(_sse_128)
+PMX_DEFINE_PROFILE_CREATORS(_avx_256)
+PMX_DEFINE_PROFILE_CREATORS(_neon_128)
+PMX_DEFINE_PROFILE_CREATORS(_altivec_128)
+
+// ---- one trampoline per dispatch name (a C function pointer carries no closure) ----------
+template <int ID>
+static parasail_result_t *tramp_f(const char *s1, const int s1Len, const char *s2, const int s2Len,
+                                  const int open, const int gap, const parasail_matrix_t *matrix)
+{
+    return run_single(spec_from_id(ID), s1, s1Len, s2, s2Len, open, gap, matrix);
+}
+template <int ID>
+static parasail_result_t *tramp_p(const parasail_profile_t *profile, const char *s2, const int s2Len,
+                                  const int open, const int gap)
+{
+    if (!profile) die("NULL profile passed to a profile alignment function", hipSuccess);
+    return run_single(spec_from_id(ID), profile->s1, profile->s1Len, s2, s2Len, open, gap, profile->matrix);
+}
+template <size_t... Is>
+static parasail_function_t *const *make_ftable(std::index_sequence<Is...>)
+{
+    static parasail_function_t *const t[] = {&tramp_f<(int)Is>...};
+    return t;
+}
+template <size_t... Is>
+static parasail_pfunction_t *const *make_ptable(std::index_sequence<Is...>)
+{
+    static parasail_pfunction_t *const t[] = {&tramp_p<(int)Is>...};
+    return t;
+}
+
+// src/aligner/mod.rs:345: NULL -> build() panics "Parasail function: {}, not found." (:353-358)
+extern "C" parasail_function_t *parasail_lookup_function(const char *funcname)
+{
+    bool prof = false;
+    const int id = parse_name(funcname, &prof);
+    if (id < 0 || prof) return nullptr;
+    return make_ftable(std::make_index_sequence<N_IDS>{})[id];
+}
+// src/aligner/mod.rs:349
+extern "C" parasail_pfunction_t *parasail_lookup_pfunction(const char *funcname)
+{
+    bool prof = false;
+    const int id = parse_name(funcname, &prof);
+    if (id < 0 || !prof) return nullptr;
+    return make_ptable(std::make_index_sequence<N_IDS>{})[id];
+}
+
+// src/aligner/mod.rs:470-481.  Cells with |i-j| > k are excluded.
+extern "C" parasail_result_t *parasail_nw_banded(const char *s1, const int s1Len, const char *s2, const int s2Len,
+                                                 const int open, const int gap, const int k,
+                                                 const parasail_matrix_t *matrix)
+{
+    RunSpec sp; memset(&sp, 0, sizeof sp);
+    sp.mode = PMX_MODE_NW; sp.band = k < 0 ? 0 : k; sp.width = 32; sp.vecflag = 0;
+    return run_single(sp, s1, s1Len, s2, s2Len, open, gap, matrix);
+}
+
+// ================================================================ traceback / CIGAR =====
+// Host-side O(qlen+rlen) walk over the trace table the GPU produced (the reference's
+// counterpart also runs on the host inside libparasail: src/alignment/mod.rs:390-419).
+// State INS (E: consumes a reference char) prints 'D', state DEL (F: consumes a query char)
+// prints 'I'  -- SAM sense with query = s1, reference = s2.  [UNPINNED, see DESIGN.md]
+static const char CIG_INS_STATE = 'D', CIG_DEL_STATE = 'I';
+
+static std::string walk_ops(const parasail_result_t *res, const char *seqA, int lena, const char *seqB, int lenb,
+                            const parasail_matrix_t *matrix, int *beg_query, int *beg_ref)
+{
+    std::string rev;
+    int i = res->end_query, j = res->end_ref;
+    const bool sw = res->flag & F_SW, sg = res->flag & F_SG;
+    if (sg) {
+        if (i + 1 == lena) for (int k = lenb - 1; k > j; --k) rev.push_back(CIG_INS_STATE);
+        else if (j + 1 == lenb) for (int k = lena - 1; k > i; --k) rev.push_back(CIG_DEL_STATE);
+    }
+    int where = PARASAIL_DIAG;
+    while (i >= 0 || j >= 0) {
+        if (i < 0) { if (sw) break; rev.push_back(CIG_INS_STATE); --j; continue; }
+        if (j < 0) { if (sw) break; rev.push_back(CIG_DEL_STATE); --i; continue; }
+        const int t = res->trace[(size_t)i * lenb + j];
+        if (where == PARASAIL_DIAG) {
+            if (t & PARASAIL_DIAG) {
+                const bool eq = matrix->mapper[(unsigned char)seqA[i]] == matrix->mapper[(unsigned char)seqB[j]];
+                rev.push_back(eq ? '=' : 'X'); --i; --j;
+            } else if (t & PARASAIL_INS) where = PARASAIL_INS;
+            else if (t & PARASAIL_DEL) where = PARASAIL_DEL;
+            else break;
+        } else if (where == PARASAIL_INS) {
+            rev.push_back(CIG_INS_STATE);
+            if (t & PARASAIL_DIAG_E) where = PARASAIL_DIAG;
+            --j;
+        } else {
+            rev.push_back(CIG_DEL_STATE);
+            if (t & PARASAIL_DIAG_F) where = PARASAIL_DIAG;
+            --i;
+        }
+    }
+    *beg_query = i + 1; *beg_ref = j + 1;
+    return std::string(rev.rbegin(), rev.rend());
+}
+
+static const char BAM_OPS[] = "MIDNSHP=X";
+
+extern "C" parasail_cigar_t *parasail_result_get_cigar(parasail_result_t *result, const char *seqA, int lena,
+                                                       const char *seqB, int lenb, const parasail_matrix_t *matrix)
+{
+    if (!result || !result->trace || !matrix || lena != result->qlen || lenb != result->rlen) return nullptr;
+    parasail_cigar_t *c = (parasail_cigar_t *)calloc(1, sizeof *c);
+    if (!c) return nullptr;
+    const std::string ops = walk_ops(result, seqA, lena, seqB, lenb, matrix, &c->beg_query, &c->beg_ref);
+    c->seq = (uint32_t *)malloc(sizeof(uint32_t) * (ops.size() + 1));
+    if (!c->seq) { free(c); return nullptr; }
+    size_t k = 0; int n = 0;
+    while (k < ops.size()) {
+        size_t run = 1;
+        while (k + run < ops.size() && ops[k + run] == ops[k]) ++run;
+        const uint32_t op = (uint32_t)(strchr(BAM_OPS, ops[k]) - BAM_OPS);
+        c->seq[n++] = ((uint32_t)run << 4) | op;
+        k += run;
+    }
+    c->len = n;
+    return c;
+}
+
+// src/alignment/mod.rs:410: the returned string is adopted by Rust with CString::from_raw
+// and must be a plain malloc block.
+extern "C" char *parasail_cigar_decode(parasail_cigar_t *cigar)
+{
+    if (!cigar) return nullptr;
+    std::string s;
+    for (int k = 0; k < cigar->len; ++k) {
+        s += std::to_string(cigar->seq[k] >> 4);
+        s.push_back(BAM_OPS[cigar->seq[k] & 0xF]);
+    }
+    char *out = (char *)malloc(s.size() + 1);
+    if (out) memcpy(out, s.c_str(), s.size() + 1);
+    return out;
+}
+extern "C" void parasail_cigar_free(parasail_cigar_t *cigar) { if (cigar) { free(cigar->seq); free(cigar); } }
+
+// src/alignment/mod.rs:356-376: the three strings are malloc blocks adopted by Rust.
+extern "C" parasail_traceback_t *parasail_result_get_traceback(parasail_result_t *result, const char *seqA, int lena,
+        const char *seqB, int lenb, const parasail_matrix_t *matrix, char match, char pos, char neg)
+{
+    if (!result || !result->trace || !matrix || lena != result->qlen || lenb != result->rlen) return nullptr;
+    int bq = 0, br = 0;
+    const std::string ops = walk_ops(result, seqA, lena, seqB, lenb, matrix, &bq, &br);
+    const size_t n = ops.size();
+    parasail_traceback_t *tb = (parasail_traceback_t *)calloc(1, sizeof *tb);
+    if (!tb) return nullptr;
+    tb->query = (char *)malloc(n + 1); tb->comp = (char *)malloc(n + 1); tb->ref = (char *)malloc(n + 1);
+    if (!tb->query || !tb->comp || !tb->ref) { free(tb->query); free(tb->comp); free(tb->ref); free(tb); return nullptr; }
+    int i = bq, j = br;
+    for (size_t k = 0; k < n; ++k) {
+        const char o = ops[k];
+        if (o == '=' || o == 'X') {
+            const int s = matrix->matrix[(size_t)matrix->size *
+                              (matrix->type == PARASAIL_MATRIX_TYPE_PSSM ? i : matrix->mapper[(unsigned char)seqA[i]]) +
+                              matrix->mapper[(unsigned char)seqB[j]]];
+            tb->query[k] = seqA[i]; tb->ref[k] = seqB[j];
+            tb->comp[k] = (o == '=') ? match : (s > 0 ? pos : neg);
+            ++i; ++j;
+        } else if (o == CIG_INS_STATE) { tb->query[k] = '-'; tb->ref[k] = seqB[j]; tb->comp[k] = ' '; ++j; }
+        else { tb->query[k] = seqA[i]; tb->ref[k] = '-'; tb->comp[k] = ' '; ++i; }
+    }
+    tb->query[n] = tb->comp[n] = tb->ref[n] = 0;
+    return tb;
+}
+extern "C" void parasail_traceback_free(parasail_traceback_t *tb)
+{
+    if (tb) { free(tb->query); free(tb->comp); free(tb->ref); free(tb); }
+}
+
+// src/alignment/mod.rs:310-344 (print_traceback): blocks of `width` columns, names padded to
+// name_width, optional summary line.
+extern "C" void parasail_traceback_generic(const char *seqA, int lena, const char *seqB, int lenb,
+        const char *nameA, const char *nameB, const parasail_matrix_t *matrix, parasail_result_t *result,
+        char match, char pos, char neg, int width, int name_width, int use_stats)
+{
+    parasail_traceback_t *tb = parasail_result_get_traceback(result, seqA, lena, seqB, lenb, matrix, match, pos, neg);
+    if (!tb) { printf("(no traceback available)\n"); return; }
+    const int n = (int)strlen(tb->query);
+    if (width <= 0) width = 80;
+    int bq = 0, br = 0;
+    (void)walk_ops(result, seqA, lena, seqB, lenb, matrix, &bq, &br);
+    int qi = bq, ri = br, nmatch = 0, ngap = 0, nmis = 0;
+    for (int k = 0; k < n; k += width) {
+        const int w = (n - k < width) ? n - k : width;
+        int qadv = 0, radv = 0;
+        for (int c = 0; c < w; ++c) {
+            if (tb->query[k + c] != '-') ++qadv;
+            if (tb->ref[k + c] != '-') ++radv;
+            if (tb->query[k + c] == '-' || tb->ref[k + c] == '-') ++ngap;
+            else if (tb->comp[k + c] == match) ++nmatch; else ++nmis;
+        }
+        printf("\n%*s %9d %.*s %9d\n", name_width, nameB ? nameB : "", ri + 1, w, tb->ref + k, ri + radv);
+        printf("%*s %9s %.*s\n", name_width, "", "", w, tb->comp + k);
+        printf("%*s %9d %.*s %9d\n", name_width, nameA ? nameA : "", qi + 1, w, tb->query + k, qi + qadv);
+        qi += qadv; ri += radv;
+    }
+    if (use_stats) {
+        printf("\nLength: %d\nIdentity:   %d/%d\nMismatches: %d/%d\nGaps:       %d/%d\nScore: %d\n",
+               n, nmatch, n, nmis, n, ngap, n, result->score);
+    }
+    parasail_traceback_free(tb);
+}
+
+// ===================================================================== SSW emulation ====
+// src/aligner/mod.rs:491-529, src/alignment/mod.rs:506-551: local alignment with begin and
+// end coordinates and a packed CIGAR.  Runs sw+trace on the GPU, walks the trace on the host.
+extern "C" parasail_result_ssw_t *parasail_ssw(const char *s1, const int s1Len, const char *s2, const int s2Len,
+                                               const int open, const int gap, const parasail_matrix_t *matrix)
+{
+    parasail_result_ssw_t *out = (parasail_result_ssw_t *)calloc(1, sizeof *out);
+    if (!out) die("calloc", hipSuccess);
+    RunSpec sp; memset(&sp, 0, sizeof sp);
+    sp.mode = PMX_MODE_SW; sp.band = -1; sp.width = 32; sp.trace = true;
+    parasail_result_t *r = run_single(sp, s1, s1Len, s2, s2Len, open, gap, matrix);
+    if (r->trace) {
+        parasail_cigar_t *c = parasail_result_get_cigar(r, s1, s1Len, s2, s2Len, matrix);
+        out->score1 = (uint16_t)(r->score > 65535 ? 65535 : (r->score < 0 ? 0 : r->score));
+        out->ref_end1 = r->end_ref; out->read_end1 = r->end_query;
+        if (c) {
+            out->ref_begin1 = c->beg_ref; out->read_begin1 = c->beg_query;
+            out->cigar = c->seq; out->cigarLen = c->len;
+            free(c);                   // the seq array is now owned by the ssw result
+        }
+    }
+    parasail_result_free(r);
+    return out;
+}
+extern "C" parasail_profile_t *parasail_ssw_init(const char *s1, const int s1Len, const parasail_matrix_t *matrix,
+                                                 const int8_t score_size)
+{
+    (void)score_size;
+    return profile_new(s1, s1Len, matrix, 1, 0);
+}
+extern "C" void parasail_result_ssw_free(parasail_result_ssw_t *r) { if (r) { free(r->cigar); free(r); } }
+
+// ============================================================================ batches ===
+static int check_cfg(const pmx_config_t *cfg)
+{
+    if (!cfg || !cfg->matrix) { set_err("null config or matrix"); return -1; }
+    if (cfg->mode < 0 || cfg->mode > 2) { set_err("bad mode %d", cfg->mode); return -1; }
+    if (cfg->width != 0 && cfg->width != 8 && cfg->width != 16 && cfg->width != 32 && cfg->width != 64) {
+        set_err("bad width %d", cfg->width); return -1;
+    }
+    if (cfg->open < 0 || cfg->extend < 0) { set_err("gap penalties are passed as positive numbers"); return -1; }
+    return 0;
+}
+
+static bool fast_sw_eligible(const pmx_config_t *cfg)
+{
+    return cfg->mode == PMX_MODE_SW && cfg->want == 0 && (cfg->width == 0 || cfg->width == 16) &&
+           cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE;
+}
+
+extern "C" const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen, int32_t max_rlen)
+{
+    if (check_cfg(cfg)) return "invalid";
+    if (fast_sw_eligible(cfg) && cfg->matrix->size <= PMX_MAX_FAST_MSIZE && max_qlen <= 2048 && max_rlen <= 60000)
+        return "pmx_sw16_kernel";
+    return "pmx_general_kernel";
+}
+
+// grow-only per-(thread,device) scratch for the general kernel's band boundary rows
+struct Scratch { void *p = nullptr; size_t cap = 0; int dev = -1; };
+static thread_local Scratch g_scratch;
+static int scratch_reserve(size_t bytes, void **out)
+{
+    int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
+    if (g_scratch.dev != dev || g_scratch.cap < bytes) {
+        if (g_scratch.p && g_scratch.dev == dev) (void)hipFree(g_scratch.p);
+        g_scratch.p = nullptr; g_scratch.cap = 0; g_scratch.dev = dev;
+        HIP_OR_RET(hipMalloc(&g_scratch.p, bytes ? bytes : 16));
+        g_scratch.cap = bytes;
+    }
+    *out = g_scratch.p;
+    return 0;
+}
+
+extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
+                                      const uint8_t *d_qbuf, const int64_t *d_qoff,
+                                      const uint8_t *d_rbuf, const int64_t *d_roff,
+                                      int32_t max_qlen, int32_t max_rlen,
+                                      pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream)
+{
+    if (check_cfg(cfg)) return -1;
+    if (n <= 0) return 0;
+    if (max_qlen <= 0 || max_rlen <= 0) { set_err("max_qlen / max_rlen must be positive"); return -1; }
+    if ((cfg->want & PMX_WANT_STATS) && !d_stats_out) { set_err("stats requested without a stats buffer"); return -1; }
+    if (cfg->want & PMX_WANT_CIGAR) { set_err("use pmx_align_batch_cigar for CIGAR output"); return -1; }
+    DevMat dm;
+    if (get_devmat(cfg->matrix, &dm)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, max_qlen, max_rlen};
+    if (fast_sw_eligible(cfg)) {
+        const int rc = pmx_launch_sw16(b, dm.d, cfg->open, cfg->extend, d_out, st, nullptr);
+        if (rc == 0) return 0;
+        if (rc < 0) { set_err("sw16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
+        // rc == 1: shape not covered by the fast kernel -> general kernel below
+    }
+    if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
+    void *bound = nullptr;
+    const size_t stride = (size_t)8 * max_rlen;
+    if (scratch_reserve((size_t)n * stride * sizeof(int32_t), &bound)) return -1;
+    PmxGeneralArgs a; memset(&a, 0, sizeof a);
+    a.qbuf = d_qbuf; a.qoff = d_qoff; a.rbuf = d_rbuf; a.roff = d_roff; a.n = n;
+    a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize; a.pssm = 0;
+    a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
+    a.bits = cfg->width;
+    a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
+    a.rec = d_out; a.stats = d_stats_out;
+    const int rc = pmx_launch_general(a, (cfg->want & PMX_WANT_STATS) != 0, st);
+    if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    return 0;
+}
+
+static void host_maxlens(int64_t n, const int64_t *off, int32_t *mx, bool *bad)
+{
+    int64_t m = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t l = off[k + 1] - off[k];
+        if (l <= 0 || l > INT32_MAX) *bad = true;
+        m = l > m ? l : m;
+    }
+    *mx = (int32_t)m;
+}
+
+extern "C" int pmx_align_batch(const pmx_config_t *cfg, int64_t n,
+                               const uint8_t *qbuf, const int64_t *qoff,
+                               const uint8_t *rbuf, const int64_t *roff,
+                               pmx_record_t *out, pmx_stats_t *stats_out)
+{
+    if (check_cfg(cfg)) return -1;
+    if (n <= 0) return 0;
+    if (!qbuf || !qoff || !rbuf || !roff || !out) { set_err("null buffer"); return -1; }
+    int32_t mq = 0, mr = 0; bool bad = false;
+    host_maxlens(n, qoff, &mq, &bad); host_maxlens(n, roff, &mr, &bad);
+    if (bad) { set_err("every sequence must have length >= 1"); return -1; }
+    const size_t qbytes = (size_t)(qoff[n] - qoff[0]), rbytes = (size_t)(roff[n] - roff[0]);
+    if (qoff[0] != 0 || roff[0] != 0) { set_err("offset arrays must start at 0"); return -1; }
+    DevBuf<uint8_t> dq, dr; DevBuf<int64_t> dqo, dro; DevBuf<pmx_record_t> drec; DevBuf<pmx_stats_t> dst;
+    dq.alloc(qbytes); dr.alloc(rbytes); dqo.alloc(n + 1); dro.alloc(n + 1); drec.alloc(n);
+    const bool stats = cfg->want & PMX_WANT_STATS;
+    if (stats) { if (!stats_out) { set_err("stats requested without a stats buffer"); return -1; } dst.alloc(n); }
+    HIP_OR_RET(hipMemcpy(dq.p, qbuf, qbytes, hipMemcpyHostToDevice));
+    HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
+    HIP_OR_RET(hipMemcpy(dqo.p, qoff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    const int rc = pmx_align_batch_device(cfg, n, dq.p, dqo.p, dr.p, dro.p, mq, mr, drec.p, stats ? dst.p : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
+    if (stats) HIP_OR_RET(hipMemcpy(stats_out, dst.p, sizeof(pmx_stats_t) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,
+                                       const uint8_t *rbuf, const int64_t *roff,
+                                       pmx_record_t *out, pmx_stats_t *stats_out)
+{
+    if (check_cfg(cfg)) return -1;
+    if (!profile) { set_err("null profile"); return -1; }
+    if (n <= 0) return 0;
+    if (profile->matrix != cfg->matrix) { set_err("profile was built with a different matrix"); return -1; }
+    if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
+    int32_t mr = 0; bool bad = false;
+    host_maxlens(n, roff, &mr, &bad);
+    if (bad || roff[0] != 0) { set_err("bad reference offsets"); return -1; }
+    const bool stats = (cfg->want & PMX_WANT_STATS) != 0;
+    if (stats && !stats_out) { set_err("stats requested without a stats buffer"); return -1; }
+    DevMat dm;
+    if (get_devmat(cfg->matrix, &dm)) return -1;
+    const size_t rbytes = (size_t)roff[n];
+    DevBuf<uint8_t> dq, dr; DevBuf<int64_t> dro; DevBuf<pmx_record_t> drec; DevBuf<pmx_stats_t> dst;
+    dq.alloc(profile->s1Len); dr.alloc(rbytes); dro.alloc(n + 1); drec.alloc(n); if (stats) dst.alloc(n);
+    HIP_OR_RET(hipMemcpy(dq.p, profile->s1, profile->s1Len, hipMemcpyHostToDevice));
+    HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
+    HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    void *bound = nullptr;
+    const size_t stride = (size_t)8 * mr;
+    if (scratch_reserve((size_t)n * stride * sizeof(int32_t), &bound)) return -1;
+    PmxGeneralArgs a; memset(&a, 0, sizeof a);
+    a.qbuf = dq.p; a.qoff = nullptr; a.shared_qlen = profile->s1Len; a.rbuf = dr.p; a.roff = dro.p; a.n = n;
+    a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
+    a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
+    a.bits = cfg->width;
+    a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
+    a.rec = drec.p; a.stats = stats ? dst.p : nullptr;
+    const int rc = pmx_launch_general(a, stats, nullptr);
+    if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
+    if (stats) HIP_OR_RET(hipMemcpy(stats_out, dst.p, sizeof(pmx_stats_t) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// CIGAR for a batch: general kernel with trace tables in HBM, then the on-device walk; only the
+// run-length ops come back to the host, which renders the text.
+extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
+                                     const uint8_t *qbuf, const int64_t *qoff,
+                                     const uint8_t *rbuf, const int64_t *roff,
+                                     pmx_record_t *out, char **cigar_buf, int64_t *cigar_off)
+{
+    if (check_cfg(cfg)) return -1;
+    if (!cigar_buf || !cigar_off) { set_err("null cigar output"); return -1; }
+    *cigar_buf = nullptr;
+    if (n <= 0) return 0;
+    if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
+    int32_t mq = 0, mr = 0; bool bad = false;
+    host_maxlens(n, qoff, &mq, &bad); host_maxlens(n, roff, &mr, &bad);
+    if (bad || qoff[0] != 0 || roff[0] != 0) { set_err("bad offsets"); return -1; }
+    DevMat dm;
+    if (get_devmat(cfg->matrix, &dm)) return -1;
+    std::vector<int64_t> tab_off(n + 1), ops_off(n + 1);
+    tab_off[0] = 0; ops_off[0] = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t ql = qoff[k + 1] - qoff[k], rl = roff[k + 1] - roff[k];
+        tab_off[k + 1] = tab_off[k] + ql * rl;
+        ops_off[k + 1] = ops_off[k] + ql + rl + 1;
+    }
+    const size_t qbytes = (size_t)qoff[n], rbytes = (size_t)roff[n];
+    DevBuf<uint8_t> dq, dr; DevBuf<int64_t> dqo, dro, dto, doo; DevBuf<pmx_record_t> drec;
+    DevBuf<int8_t> dtrace; DevBuf<uint32_t> dops; DevBuf<int32_t> dnops, dbeg;
+    dq.alloc(qbytes); dr.alloc(rbytes); dqo.alloc(n + 1); dro.alloc(n + 1); dto.alloc(n + 1); doo.alloc(n + 1);
+    drec.alloc(n); dtrace.alloc((size_t)tab_off[n]); dops.alloc((size_t)ops_off[n]); dnops.alloc(n); dbeg.alloc(2 * n);
+    HIP_OR_RET(hipMemcpy(dq.p, qbuf, qbytes, hipMemcpyHostToDevice));
+    HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
+    HIP_OR_RET(hipMemcpy(dqo.p, qoff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    HIP_OR_RET(hipMemcpy(dto.p, tab_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    HIP_OR_RET(hipMemcpy(doo.p, ops_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    void *bound = nullptr;
+    const size_t stride = (size_t)8 * mr;
+    if (scratch_reserve((size_t)n * stride * sizeof(int32_t), &bound)) return -1;
+    PmxGeneralArgs a; memset(&a, 0, sizeof a);
+    a.qbuf = dq.p; a.qoff = dqo.p; a.rbuf = dr.p; a.roff = dro.p; a.n = n;
+    a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
+    a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
+    a.bits = cfg->width;
+    a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
+    a.rec = drec.p; a.tab_off = dto.p; a.trace_table = dtrace.p;
+    int rc = pmx_launch_general(a, false, nullptr);
+    if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    PmxWalkArgs w; memset(&w, 0, sizeof w);
+    w.qbuf = dq.p; w.qoff = dqo.p; w.rbuf = dr.p; w.roff = dro.p; w.n = n;
+    w.mapper = dm.d.mapper; w.mode = cfg->mode; w.trace_table = dtrace.p; w.tab_off = dto.p; w.rec = drec.p;
+    w.ops = dops.p; w.ops_off = doo.p; w.nops = dnops.p; w.beg = dbeg.p;
+    rc = pmx_launch_walk(w, nullptr);
+    if (rc) { set_err("walk kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    std::vector<uint32_t> ops((size_t)ops_off[n]); std::vector<int32_t> nops(n);
+    HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
+    HIP_OR_RET(hipMemcpy(ops.data(), dops.p, sizeof(uint32_t) * ops.size(), hipMemcpyDeviceToHost));
+    HIP_OR_RET(hipMemcpy(nops.data(), dnops.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    std::string text;
+    cigar_off[0] = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        for (int t = 0; t < nops[k]; ++t) {
+            const uint32_t o = ops[(size_t)ops_off[k] + t];
+            text += std::to_string(o >> 4);
+            text.push_back(BAM_OPS[o & 0xF]);
+        }
+        cigar_off[k + 1] = (int64_t)text.size();
+    }
+    *cigar_buf = (char *)malloc(text.size() + 1);
+    if (!*cigar_buf) { set_err("out of memory"); return -1; }
+    memcpy(*cigar_buf, text.c_str(), text.size() + 1);
+    return 0;
+}
+
+extern "C" void pmx_free(void *p) { free(p); }

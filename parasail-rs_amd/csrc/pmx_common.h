@@ -1,0 +1,68 @@
+// pmx_common.h -- internal declarations shared by the HIP kernels and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/parasail_amd.h"
+
+#define PMX_MAX_FAST_MSIZE 32      // fast kernels stage the matrix in LDS as int16[msize*msize]
+
+// Device-side view of a substitution matrix (built once per parasail_matrix_t, cached).
+struct PmxDevMatrix {
+    const int16_t *scores;   // [msize*msize], scores[qsym*msize + rsym]   (device)
+    const uint8_t *mapper;   // [256] byte -> symbol index                  (device)
+    int msize;
+    int min, max;
+};
+
+// Batch of pairs, device-resident, packed layout of include/parasail_amd.h.
+struct PmxBatch {
+    const uint8_t *qbuf; const int64_t *qoff;
+    const uint8_t *rbuf; const int64_t *roff;
+    int64_t n;
+    int max_qlen, max_rlen;
+};
+
+// Fast path: local alignment, score + end positions, packed int16 lanes.
+// Returns 0 if launched, 1 if the shape is not supported by any instantiation (caller falls
+// through to the general kernel), <0 on a HIP error.
+int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
+                    pmx_record_t *d_out, hipStream_t stream, const char **kernel_name);
+
+// ---- general kernel (all modes, stats, tables, rows/cols, trace, band) -------------------
+struct PmxGeneralArgs {
+    // inputs
+    const uint8_t *qbuf; const int64_t *qoff;     // qoff == nullptr: one shared query of shared_qlen bytes at qbuf
+    const uint8_t *rbuf; const int64_t *roff;
+    long long n;
+    int shared_qlen;
+    const int16_t *scores; const uint8_t *mapper; int msize;
+    int mat_rows;             // rows of `scores`: msize for a square matrix, query length for a PSSM
+    int pssm;                 // 1: row of `scores` is the query position, not the query symbol
+    int mode, sg_flags, open, ext;
+    int band;                 // < 0: no band; else cells with |i-j| > band are excluded (nw_banded)
+    int bits;                 // 0/32/64: no range check; 8 or 16: report saturation of that range
+    // per-pair scratch: boundary row between 64-row bands, 8 ints per reference column
+    int32_t *bound; long long bound_stride;       // ints per pair
+    // outputs (device); any may be null
+    pmx_record_t *rec; pmx_stats_t *stats;
+    // table-like outputs: cell offset of pair k is tab_off[k] (nullptr -> pair 0 at 0, n must be 1)
+    const int64_t *tab_off;
+    int32_t *score_table, *matches_table, *similar_table, *length_table;
+    int8_t *trace_table;
+    // row/col outputs: row offset = roff[k], col offset = qoff[k] (or 0 for n == 1)
+    int32_t *score_row, *matches_row, *similar_row, *length_row;
+    int32_t *score_col, *matches_col, *similar_col, *length_col;
+};
+int pmx_launch_general(const PmxGeneralArgs &a, bool want_stats, hipStream_t stream);
+
+// On-device traceback walk: trace tables -> run-length ops (BAM-encoded uint32 per run).
+// ops_off[k] = first slot of pair k in `ops` (capacity qlen+rlen each), nops[k] = runs written.
+struct PmxWalkArgs {
+    const uint8_t *qbuf; const int64_t *qoff; const uint8_t *rbuf; const int64_t *roff;
+    long long n; int shared_qlen;
+    const uint8_t *mapper; int mode;
+    const int8_t *trace_table; const int64_t *tab_off;
+    const pmx_record_t *rec;
+    uint32_t *ops; const int64_t *ops_off; int32_t *nops; int32_t *beg; /* 2 per pair */
+};
+int pmx_launch_walk(const PmxWalkArgs &a, hipStream_t stream);

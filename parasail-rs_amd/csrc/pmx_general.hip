@@ -1,0 +1,334 @@
+// pmx_general.hip -- the general DP kernel: every mode (nw / sg with any free-end set / sw),
+// optional statistics (matches, similar, length), full tables, last row/col, trace table,
+// banded nw, 32-bit arithmetic.  gfx950 only.
+//
+// It backs every `parasail_*` dispatch name (name grammar /root/reference/src/aligner/mod.rs:
+// 319-329) that the packed-int16 fast kernels do not cover, and produces the memory layouts the
+// result accessors hand out: tables [query_len][ref_len] int32 row-major
+// (src/alignment/table.rs:4-9), 1-byte trace cells with the TraceFlags bit values
+// (src/alignment/table.rs:127-142), rows of ref_len and cols of query_len entries
+// (src/alignment/mod.rs:195-288).
+//
+// Mapping: one 64-lane wave per pair.  The query is cut into bands of 64 rows; inside a band
+// lane l owns row band*64+l and keeps that row's state (H of the previous column, E, and their
+// statistics) in registers.  The wave sweeps the band along anti-diagonals: at step t lane l
+// computes column t-l, taking H/F (and stats) of the row above from lane l-1 through a
+// wave shuffle.  The band's last row is parked in a per-pair boundary buffer in HBM
+// (8 ints per reference column) and picked up by lane 0 of the next band.
+//
+// Recurrences, boundary values and every tie-break are the ones written down in
+// oracle/pmx_oracle.c (the checker); they are restated here, not shared.
+#include "pmx_common.h"
+
+#define NEG_INF (INT32_MIN / 2)
+
+#define T_INS 1
+#define T_DEL 2
+#define T_DIAG 4
+#define T_DIAG_E 8
+#define T_INS_E 16
+#define T_DIAG_F 32
+#define T_DEL_F 64
+
+struct Cand { int H, i, j, M, S, L; };
+
+// true if a should replace b under "larger H, then smaller j, then smaller i"
+__device__ __forceinline__ bool better_sw(const Cand &a, const Cand &b)
+{
+    if (a.H != b.H) return a.H > b.H;
+    if (a.j != b.j) return a.j < b.j;
+    return a.i < b.i;
+}
+__device__ __forceinline__ bool better_minj(const Cand &a, const Cand &b)
+{
+    if (a.H != b.H) return a.H > b.H;
+    return a.j < b.j;
+}
+__device__ __forceinline__ bool better_mini(const Cand &a, const Cand &b)
+{
+    if (a.H != b.H) return a.H > b.H;
+    return a.i < b.i;
+}
+__device__ __forceinline__ Cand shfl_cand(const Cand &c, int off)
+{
+    Cand o;
+    o.H = __shfl_xor(c.H, off, 64); o.i = __shfl_xor(c.i, off, 64); o.j = __shfl_xor(c.j, off, 64);
+    o.M = __shfl_xor(c.M, off, 64); o.S = __shfl_xor(c.S, off, 64); o.L = __shfl_xor(c.L, off, 64);
+    return o;
+}
+
+template <bool STATS, bool OUT>
+__global__ __launch_bounds__(64)
+void pmx_general_kernel(const PmxGeneralArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int16_t *mat = reinterpret_cast<int16_t *>(lds);
+    const int lane = threadIdx.x;
+    const long long pair = blockIdx.x;
+    const int msize = a.msize;
+
+    for (int i = lane; i < a.mat_rows * msize; i += 64) mat[i] = a.scores[i];
+    __syncthreads();
+
+    long long qb, rb; int ql, rl;
+    if (a.qoff) { qb = a.qoff[pair]; ql = (int)(a.qoff[pair + 1] - qb); }
+    else { qb = 0; ql = a.shared_qlen; }
+    rb = a.roff[pair]; rl = (int)(a.roff[pair + 1] - rb);
+    const uint8_t *q = a.qbuf + qb, *r = a.rbuf + rb;
+    const long long tab0 = a.tab_off ? a.tab_off[pair] : 0;
+    const long long row0 = (a.n > 1) ? rb : 0;     // row outputs packed like the references
+    const long long col0 = (a.n > 1 && a.qoff) ? qb : (a.qoff ? 0 : pair * (long long)ql);
+    volatile int32_t *bound = a.bound + pair * a.bound_stride;
+
+    const int mode = a.mode, open = a.open, ext = a.ext, band_w = a.band;
+    const bool s1_beg = mode == PMX_MODE_SG && (a.sg_flags & PMX_SG_QB);
+    const bool s1_end = mode == PMX_MODE_SG && (a.sg_flags & PMX_SG_QE);
+    const bool s2_beg = mode == PMX_MODE_SG && (a.sg_flags & PMX_SG_DB);
+    const bool s2_end = mode == PMX_MODE_SG && (a.sg_flags & PMX_SG_DE);
+    const bool col_pen = mode == PMX_MODE_NW || (mode == PMX_MODE_SG && !s1_beg);  // H(i,-1) penalised
+    const bool row_pen = mode == PMX_MODE_NW || (mode == PMX_MODE_SG && !s2_beg);  // H(-1,j) penalised
+
+    Cand best_sw = {NEG_INF, 0, 0, 0, 0, 0};      // sw: global best
+    Cand best_row = {NEG_INF, 0, 0, 0, 0, 0};     // sg: best of the last row
+    Cand best_col = {NEG_INF, 0, 0, 0, 0, 0};     // sg: best of the last column
+    Cand corner = {NEG_INF, 0, 0, 0, 0, 0};
+    int hmin = 0, hmax = 0;
+
+    const int nbands = (ql + 63) / 64;
+    for (int bandi = 0; bandi < nbands; ++bandi) {
+        const int i = bandi * 64 + lane;
+        const bool row_ok = i < ql;
+        const int qsym = row_ok ? a.mapper[q[i]] : 0;
+        const int16_t *mrow = mat + (a.pssm ? (row_ok ? i : 0) : qsym) * msize;
+        // left boundary H(i,-1) and the diagonal seed H(i-1,-1)
+        int leftH = col_pen ? -(open + i * ext) : 0;
+        int leftM = 0, leftS = 0, leftL = col_pen ? i + 1 : 0;
+        int diagH = (i == 0) ? 0 : (col_pen ? -(open + (i - 1) * ext) : 0);
+        int diagM = 0, diagS = 0, diagL = (i == 0) ? 0 : (col_pen ? i : 0);
+        if (row_ok) { hmin = min(hmin, leftH); }
+        int E = NEG_INF, EM = 0, ES = 0, EL = 0;
+        // what this lane hands to the lane below: H(i,j), F(i,j) and stats
+        int oH = NEG_INF, oF = NEG_INF, oHM = 0, oHS = 0, oHL = 0, oFM = 0, oFS = 0, oFL = 0;
+
+        const int steps = rl + 63;
+        for (int t = 0; t < steps; ++t) {
+            const int j = t - lane;
+            // --- values of the row above for column j (produced one step ago by lane-1) ---
+            int upH = __shfl_up(oH, 1, 64), upF = __shfl_up(oF, 1, 64);
+            int upHM = 0, upHS = 0, upHL = 0, upFM = 0, upFS = 0, upFL = 0;
+            if (STATS) {
+                upHM = __shfl_up(oHM, 1, 64); upHS = __shfl_up(oHS, 1, 64); upHL = __shfl_up(oHL, 1, 64);
+                upFM = __shfl_up(oFM, 1, 64); upFS = __shfl_up(oFS, 1, 64); upFL = __shfl_up(oFL, 1, 64);
+            }
+            const bool active = row_ok && j >= 0 && j < rl;
+            if (lane == 0 && j < rl) {
+                if (bandi == 0) {
+                    upH = row_pen ? -(open + j * ext) : 0;
+                    upF = NEG_INF;
+                    upHM = upHS = 0; upHL = row_pen ? j + 1 : 0;
+                    upFM = upFS = upFL = 0;
+                    hmin = min(hmin, upH);
+                } else {
+                    upH = bound[8LL * j + 0]; upF = bound[8LL * j + 1];
+                    if (STATS) {
+                        upHM = bound[8LL * j + 2]; upHS = bound[8LL * j + 3]; upHL = bound[8LL * j + 4];
+                        upFM = bound[8LL * j + 5]; upFS = bound[8LL * j + 6]; upFL = bound[8LL * j + 7];
+                    }
+                }
+            }
+            if (active) {
+                const int rsym = a.mapper[r[j]];
+                const int s = mrow[rsym];
+                int T = 0;
+                int F, FM, FS, FL;
+                {
+                    const int F_opn = upH - open, F_ext = upF - ext;
+                    if (F_opn > F_ext) { F = F_opn; FM = upHM; FS = upHS; FL = upHL + 1; T |= T_DIAG_F; }
+                    else { F = F_ext; FM = upFM; FS = upFS; FL = upFL + 1; T |= T_DEL_F; }
+                    if (F < NEG_INF) F = NEG_INF;
+                }
+                {
+                    const int E_opn = leftH - open, E_ext = E - ext;
+                    if (E_opn > E_ext) { E = E_opn; EM = leftM; ES = leftS; EL = leftL + 1; T |= T_DIAG_E; }
+                    else { E = E_ext; EL = EL + 1; T |= T_INS_E; }
+                    if (E < NEG_INF) E = NEG_INF;
+                }
+                const int H_dag = diagH + s;
+                int H, HM, HS, HL;
+                if (H_dag >= E && H_dag >= F) {
+                    H = H_dag; HM = diagM + (qsym == rsym); HS = diagS + (s > 0); HL = diagL + 1; T |= T_DIAG;
+                } else if (F >= E) {
+                    H = F; HM = FM; HS = FS; HL = FL; T |= T_DEL;
+                } else {
+                    H = E; HM = EM; HS = ES; HL = EL; T |= T_INS;
+                }
+                if (mode == PMX_MODE_SW && H <= 0) {
+                    H = 0; HM = HS = HL = 0; T &= ~(T_INS | T_DEL | T_DIAG);
+                }
+                if (band_w >= 0 && (i - j > band_w || j - i > band_w)) {
+                    H = NEG_INF; E = NEG_INF; F = NEG_INF; HM = HS = HL = 0;
+                }
+                hmax = max(hmax, H);
+                if (band_w < 0) hmin = min(hmin, H);
+
+                if (OUT) {
+                    const long long c = tab0 + (long long)i * rl + j;
+                    if (a.score_table) a.score_table[c] = H;
+                    if (STATS) {
+                        if (a.matches_table) a.matches_table[c] = HM;
+                        if (a.similar_table) a.similar_table[c] = HS;
+                        if (a.length_table) a.length_table[c] = HL;
+                    }
+                    if (a.trace_table) a.trace_table[c] = (int8_t)T;
+                    if (i == ql - 1) {
+                        if (a.score_row) a.score_row[row0 + j] = H;
+                        if (STATS) {
+                            if (a.matches_row) a.matches_row[row0 + j] = HM;
+                            if (a.similar_row) a.similar_row[row0 + j] = HS;
+                            if (a.length_row) a.length_row[row0 + j] = HL;
+                        }
+                    }
+                    if (j == rl - 1) {
+                        if (a.score_col) a.score_col[col0 + i] = H;
+                        if (STATS) {
+                            if (a.matches_col) a.matches_col[col0 + i] = HM;
+                            if (a.similar_col) a.similar_col[col0 + i] = HS;
+                            if (a.length_col) a.length_col[col0 + i] = HL;
+                        }
+                    }
+                }
+                const Cand c = {H, i, j, HM, HS, HL};
+                if (mode == PMX_MODE_SW) { if (better_sw(c, best_sw)) best_sw = c; }
+                else {
+                    if (i == ql - 1 && j == rl - 1) corner = c;
+                    if (i == ql - 1 && s2_end && c.H > best_row.H) best_row = c;   // j ascends: first max kept
+                    if (j == rl - 1 && s1_end && c.H > best_col.H) best_col = c;   // i ascends: first max kept
+                }
+                // state for the next column / the lane below
+                diagH = upH; diagM = upHM; diagS = upHS; diagL = upHL;
+                leftH = H; leftM = HM; leftS = HS; leftL = HL;
+                oH = H; oF = F; oHM = HM; oHS = HS; oHL = HL; oFM = FM; oFS = FS; oFL = FL;
+                if (lane == 63 && bandi + 1 < nbands) {
+                    bound[8LL * j + 0] = H; bound[8LL * j + 1] = F;
+                    if (STATS) {
+                        bound[8LL * j + 2] = HM; bound[8LL * j + 3] = HS; bound[8LL * j + 4] = HL;
+                        bound[8LL * j + 5] = FM; bound[8LL * j + 6] = FS; bound[8LL * j + 7] = FL;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- wave reduction ---------------------------------------------------------------
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Cand o = shfl_cand(best_sw, off); if (better_sw(o, best_sw)) best_sw = o;
+        o = shfl_cand(best_row, off); if (better_minj(o, best_row)) best_row = o;
+        o = shfl_cand(best_col, off); if (better_mini(o, best_col)) best_col = o;
+        o = shfl_cand(corner, off); if (o.H > corner.H) corner = o;
+        hmin = min(hmin, __shfl_xor(hmin, off, 64));
+        hmax = max(hmax, __shfl_xor(hmax, off, 64));
+    }
+    if (lane == 0) {
+        Cand res;
+        if (mode == PMX_MODE_SW) res = best_sw;
+        else if (mode == PMX_MODE_NW || (!s1_end && !s2_end)) res = corner;
+        else {
+            res = best_row;                                   // NEG_INF when the ref end is not free
+            if (s1_end && best_col.H > res.H) res = best_col; // last column must be strictly better
+        }
+        pmx_record_t rec;
+        rec.score = res.H; rec.end_query = res.i; rec.end_ref = res.j; rec.flags = 0;
+        if (a.bits == 8 && (hmax > 127 || hmin < -128)) rec.flags |= PMX_FLAG_SATURATED;
+        if (a.bits == 16 && (hmax > 32767 || hmin < -32768)) rec.flags |= PMX_FLAG_SATURATED;
+        if (a.rec) a.rec[pair] = rec;
+        if (STATS && a.stats) { pmx_stats_t st = {res.M, res.S, res.L}; a.stats[pair] = st; }
+    }
+}
+
+int pmx_launch_general(const PmxGeneralArgs &a, bool want_stats, hipStream_t stream)
+{
+    if (a.n <= 0) return 0;
+    const size_t lds = (size_t)a.mat_rows * a.msize * 2;
+    if (lds > 64 * 1024) return 1;
+    const bool out = a.score_table || a.trace_table || a.score_row || a.score_col ||
+                     a.matches_table || a.similar_table || a.length_table;
+    dim3 grid((unsigned)a.n), block(64);
+    if (want_stats) {
+        if (out) hipLaunchKernelGGL((pmx_general_kernel<true, true>), grid, block, lds, stream, a);
+        else     hipLaunchKernelGGL((pmx_general_kernel<true, false>), grid, block, lds, stream, a);
+    } else {
+        if (out) hipLaunchKernelGGL((pmx_general_kernel<false, true>), grid, block, lds, stream, a);
+        else     hipLaunchKernelGGL((pmx_general_kernel<false, false>), grid, block, lds, stream, a);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---- traceback walk on the device: one lane per pair ---------------------------------------
+// Restates oracle/pmx_oracle.c:orc_walk (checker) for the product path; emits run-length BAM ops
+// in reverse, then reverses in place.  '=' 7, 'X' 8, 'I' 1, 'D' 2.
+#define OP_I 1u
+#define OP_D 2u
+#define OP_EQ 7u
+#define OP_X 8u
+// state INS (E, consumes a reference character) prints 'D'; state DEL (F, consumes a query
+// character) prints 'I' (SAM sense with query = s1, reference = s2).
+#define OP_FOR_INS_STATE OP_D
+#define OP_FOR_DEL_STATE OP_I
+
+__global__ void pmx_walk_kernel(const PmxWalkArgs a)
+{
+    const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= a.n) return;
+    long long qb; int ql;
+    if (a.qoff) { qb = a.qoff[pair]; ql = (int)(a.qoff[pair + 1] - qb); } else { qb = 0; ql = a.shared_qlen; }
+    const long long rb = a.roff[pair]; const int rl = (int)(a.roff[pair + 1] - rb);
+    const uint8_t *q = a.qbuf + qb, *r = a.rbuf + rb;
+    const int8_t *tr = a.trace_table + (a.tab_off ? a.tab_off[pair] : 0);
+    uint32_t *ops = a.ops + a.ops_off[pair];
+    const pmx_record_t rec = a.rec[pair];
+    int i = rec.end_query, j = rec.end_ref, n = 0;
+    uint32_t cur_op = 0, cur_len = 0;
+    int where = T_DIAG;
+    auto emit = [&](uint32_t op) {
+        if (op == cur_op) { ++cur_len; }
+        else { if (cur_len) ops[n++] = (cur_len << 4) | cur_op; cur_op = op; cur_len = 1; }
+    };
+    if (a.mode == PMX_MODE_SG) {
+        if (i + 1 == ql) { for (int k = rl - 1; k > j; --k) emit(OP_FOR_INS_STATE); }
+        else if (j + 1 == rl) { for (int k = ql - 1; k > i; --k) emit(OP_FOR_DEL_STATE); }
+    }
+    while (i >= 0 || j >= 0) {
+        if (i < 0) { if (a.mode == PMX_MODE_SW) break; emit(OP_FOR_INS_STATE); --j; continue; }
+        if (j < 0) { if (a.mode == PMX_MODE_SW) break; emit(OP_FOR_DEL_STATE); --i; continue; }
+        const int t = tr[(long long)i * rl + j];
+        if (where == T_DIAG) {
+            if (t & T_DIAG) { emit(a.mapper[q[i]] == a.mapper[r[j]] ? OP_EQ : OP_X); --i; --j; }
+            else if (t & T_INS) where = T_INS;
+            else if (t & T_DEL) where = T_DEL;
+            else break;
+        } else if (where == T_INS) {
+            emit(OP_FOR_INS_STATE);
+            if (t & T_DIAG_E) where = T_DIAG;
+            --j;
+        } else {
+            emit(OP_FOR_DEL_STATE);
+            if (t & T_DIAG_F) where = T_DIAG;
+            --i;
+        }
+    }
+    if (cur_len) ops[n++] = (cur_len << 4) | cur_op;
+    for (int k = 0; k < n / 2; ++k) { uint32_t tmp = ops[k]; ops[k] = ops[n - 1 - k]; ops[n - 1 - k] = tmp; }
+    a.nops[pair] = n;
+    a.beg[2 * pair] = i + 1; a.beg[2 * pair + 1] = j + 1;
+}
+
+int pmx_launch_walk(const PmxWalkArgs &a, hipStream_t stream)
+{
+    if (a.n <= 0) return 0;
+    const unsigned blocks = (unsigned)((a.n + 63) / 64);
+    hipLaunchKernelGGL(pmx_walk_kernel, dim3(blocks), dim3(64), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}

@@ -1,0 +1,285 @@
+// pmx_sw16.hip -- the hot kernel: local (Smith-Waterman) affine-gap alignment, score and
+// end positions, many independent pairs per launch.  gfx950 only.
+//
+// Replaces what `Aligner::align()` reaches for the dispatch names `sw_striped_16` /
+// `sw_striped_sat` (name grammar /root/reference/src/aligner/mod.rs:319-329, call site
+// :411-422): the parasail CPU kernel fills the DP matrix column by column with 8/16 SIMD
+// lanes striped over the query.  Here the mapping is re-designed for a 64-lane wavefront:
+//
+//   * A group of G adjacent lanes owns one *slot*.  A slot carries TWO pairs at once: every
+//     32-bit register holds pair A's value in its low int16 and pair B's in its high int16, so
+//     every v_pk_{add,sub,max}_i16 updates two DP cells.
+//   * Lane g of the group keeps R consecutive query rows [g*R, g*R+R) of both pairs entirely in
+//     VGPRs (H of the previous column, E) and walks the reference left to right, one column per
+//     step, one step behind lane g-1 (a systolic array over the lanes).  The F chain runs down
+//     the R rows inside the lane; the last row's H and F go to lane g+1 through one DPP
+//     row_shr:1 / wave_shr:1 move each per step.  There is no lazy-F loop and no barrier.
+//   * The per-pair query profile (score of every query row against every reference symbol,
+//     int16) is built in LDS once; per step a lane fetches the R scores of its rows for the
+//     current reference symbol of pair A and of pair B and interleaves them with v_perm_b32.
+//   * H lives in an offset domain (value - 32768): v_pk_add_i16 with clamp then saturates at
+//     "zero" for free, which removes the max(.,0) of local alignment, and gives an exact range
+//     of 0..65535 so that int16 overflow (score > 32767) can be reported like the reference's
+//     `is_saturated` (src/alignment/mod.rs:436-440).
+//   * End position = first maximum in column-major order (smallest end_ref, then smallest
+//     end_query): each lane keeps its running best, the column where it was first reached and a
+//     copy of its R-row H strip at that column (v_bfi_b32 under a per-half mask); a group
+//     reduction at the end picks (score desc, column asc, row asc).
+//
+// Padding never needs masks: reference positions outside [0, rlen) use a pad symbol whose
+// profile row is -32768 (H falls to zero, gaps only decay), padded query rows score 0; neither
+// can strictly exceed the true maximum nor precede its first occurrence in column-major order.
+#include "pmx_common.h"
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+#define PK(x)  __builtin_bit_cast(v2s, (int)(x))
+#define I32(x) __builtin_bit_cast(int, (x))
+
+__device__ __forceinline__ v2s pk_adds(v2s a, v2s b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ __forceinline__ v2s pk_subs(v2s a, v2s b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ __forceinline__ v2s pk_max(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
+
+// value of lane-1 inside a G-lane group; lane 0 of the group receives `neutral`.
+template <int G>
+__device__ __forceinline__ int group_shift_up(int x, int neutral, int g)
+{
+    if (G == 1) return neutral;
+    if (G <= 16) {
+        int r = __builtin_amdgcn_update_dpp(neutral, x, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+        if (G < 16) r = (g == 0) ? neutral : r;
+        return r;
+    } else {
+        int r = __builtin_amdgcn_update_dpp(neutral, x, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+        if (G < 64) r = (g == 0) ? neutral : r;
+        return r;
+    }
+}
+
+#define NEG16 ((short)-32768)
+#define FLOOR2 0x80008000   // both halves = -32768 = "zero" of the offset domain
+
+template <int G, int R>
+__global__ __launch_bounds__(64)
+void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
+                     const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
+                     long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
+                     int msize, int open, int ext, int RP /* rsym stride, bytes */,
+                     pmx_record_t *__restrict__ out)
+{
+    static_assert(R % 2 == 0, "rows are stored two per dword");
+    constexpr int QP = G * R;            // padded query rows per pair
+    constexpr int QP2 = QP / 2;          // dwords per profile row
+    constexpr int SLOTS = 64 / G;
+    constexpr int NP = 2 * SLOTS;        // pairs per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int lane = threadIdx.x;
+    const int g = lane % G;
+    const int slot = lane / G;
+    const int MS1 = msize + 1;           // + pad symbol row
+    const int PROF_STRIDE = MS1 * QP * 2;   // bytes per pair
+
+    // LDS carve: [prof NP][rsym NP*RP][qsym NP*QP][mat msize*msize*2][map 256]
+    int16_t *prof = reinterpret_cast<int16_t *>(lds);
+    unsigned char *rsym = lds + NP * PROF_STRIDE;
+    unsigned char *qsym = rsym + NP * RP;
+    int16_t *mat = reinterpret_cast<int16_t *>(qsym + NP * QP);
+    unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
+
+    const long long pair0 = (long long)blockIdx.x * NP;
+
+    // ---- stage matrix + mapper -------------------------------------------------------
+    for (int i = lane; i < msize * msize; i += 64) mat[i] = gmat[i];
+    for (int i = lane; i < 256; i += 64) map[i] = gmap[i];
+    __syncthreads();
+
+    // ---- sequences -> symbols ---------------------------------------------------------
+    int max_rlen = 0;
+    for (int p = 0; p < NP; ++p) {
+        long long pi = pair0 + p; if (pi >= n) pi = n - 1;
+        const long long qb = qoff[pi], rb = roff[pi];
+        const int ql = (int)(qoff[pi + 1] - qb), rl = (int)(roff[pi + 1] - rb);
+        max_rlen = rl > max_rlen ? rl : max_rlen;
+        for (int i = lane; i < QP; i += 64)
+            qsym[p * QP + i] = (i < ql) ? map[qbuf[qb + i]] : (unsigned char)0xFF;
+        for (int j = lane; j < RP; j += 64) {
+            const int jj = j - (G - 1);
+            rsym[p * RP + j] = (jj >= 0 && jj < rl) ? map[rbuf[rb + jj]] : (unsigned char)msize;
+        }
+    }
+    __syncthreads();
+
+    // ---- query profiles ---------------------------------------------------------------
+    for (int p = 0; p < NP; ++p) {
+        int *pp = reinterpret_cast<int *>(prof) + p * (PROF_STRIDE / 4);
+        const unsigned char *qs = qsym + p * QP;
+        for (int idx = lane; idx < MS1 * QP2; idx += 64) {
+            const int sym = idx / QP2, rp = idx - sym * QP2;
+            int v;
+            if (sym == msize) v = FLOOR2;
+            else {
+                const int q0 = qs[2 * rp], q1 = qs[2 * rp + 1];
+                const int s0 = (q0 == 0xFF) ? 0 : mat[q0 * msize + sym];
+                const int s1 = (q1 == 0xFF) ? 0 : mat[q1 * msize + sym];
+                v = (s0 & 0xFFFF) | (s1 << 16);
+            }
+            pp[idx] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- systolic sweep ---------------------------------------------------------------
+    const int pA = 2 * slot, pB = 2 * slot + 1;
+    const unsigned char *profA = lds + pA * PROF_STRIDE + g * (R * 2);
+    const unsigned char *profB = lds + pB * PROF_STRIDE + g * (R * 2);
+    const unsigned char *rsA = rsym + pA * RP + (G - 1) - g;
+    const unsigned char *rsB = rsym + pB * RP + (G - 1) - g;
+    const int SYMSTRIDE = QP * 2;
+
+    const v2s vOpen = PK((open & 0xFFFF) | (open << 16));
+    const v2s vExt = PK((ext & 0xFFFF) | (ext << 16));
+    const v2s vFloor = PK(FLOOR2);
+
+    v2s Hprev[R], E[R], Hsave[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { Hprev[k] = vFloor; E[k] = vFloor; Hsave[k] = vFloor; }
+    v2s best = vFloor;
+    int bestcol = 0;
+    int jj = ((-g) & 0xFFFF) * 0x00010001;    // packed column index of this lane
+    int Hout = FLOOR2, Fout = FLOOR2;         // last-row H and outgoing F of the previous step
+    v2s diag0 = vFloor;                       // H(i0-1, j-1)
+
+    const int T = max_rlen + G - 1;
+    for (int t = 0; t < T; ++t) {
+        const int symA = rsA[t], symB = rsB[t];
+        const int *sa = reinterpret_cast<const int *>(profA + symA * SYMSTRIDE);
+        const int *sb = reinterpret_cast<const int *>(profB + symB * SYMSTRIDE);
+        int wa[R / 2], wb[R / 2];
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
+
+        const int Hin = group_shift_up<G>(Hout, FLOOR2, g);   // H(i0-1, j)
+        v2s F = PK(group_shift_up<G>(Fout, FLOOR2, g));       // F(i0, j)
+        v2s diag = diag0;
+        diag0 = PK(Hin);
+        v2s colmax = vFloor;
+        v2s H;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int w0 = wa[k / 2], w1 = wb[k / 2];
+            const v2s s = PK(__builtin_amdgcn_perm(w1, w0, (k & 1) ? 0x07060302 : 0x05040100));
+            H = pk_adds(diag, s);
+            H = pk_max(H, E[k]);
+            H = pk_max(H, F);
+            const v2s Ho = pk_subs(H, vOpen);
+            E[k] = pk_max(pk_subs(E[k], vExt), Ho);
+            F = pk_max(pk_subs(F, vExt), Ho);
+            diag = Hprev[k];
+            Hprev[k] = H;
+            colmax = pk_max(colmax, H);
+        }
+        Hout = I32(H);
+        Fout = I32(F);
+
+        // end-position bookkeeping: strictly greater than the lane's best so far?
+        const v2s nb = pk_max(best, colmax);
+        const int x = I32(nb) ^ I32(best);
+        typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+        const v2u one2 = {1, 1}, zero2 = {0, 0};
+        const v2u xm = zero2 - __builtin_elementwise_min(__builtin_bit_cast(v2u, x), one2);
+        const int m = __builtin_bit_cast(int, xm);        // 0xFFFF in every improved half
+        bestcol = (m & jj) | (~m & bestcol);
+#pragma unroll
+        for (int k = 0; k < R; ++k) Hsave[k] = PK((m & I32(Hprev[k])) | (~m & I32(Hsave[k])));
+        best = nb;
+        jj += 0x00010001;
+    }
+
+    // ---- per lane: first row of the saved strip that holds the best ---------------------
+    unsigned long long keyA, keyB;
+    {
+        const int bA = (short)(I32(best) & 0xFFFF), bB = (short)(I32(best) >> 16);
+        int kA = 0, kB = 0;
+#pragma unroll
+        for (int k = R - 1; k >= 0; --k) {
+            if ((short)(I32(Hsave[k]) & 0xFFFF) == bA) kA = k;
+            if ((short)(I32(Hsave[k]) >> 16) == bB) kB = k;
+        }
+        const unsigned sA = (unsigned)(bA + 32768), sB = (unsigned)(bB + 32768);
+        const unsigned cA = bestcol & 0xFFFF, cB = (unsigned)bestcol >> 16;
+        const unsigned rA = g * R + kA, rB = g * R + kB;
+        keyA = ((unsigned long long)sA << 32) | ((0xFFFFu - cA) << 16) | (0xFFFFu - rA);
+        keyB = ((unsigned long long)sB << 32) | ((0xFFFFu - cB) << 16) | (0xFFFFu - rB);
+    }
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) {
+        const unsigned long long oa = __shfl_xor(keyA, off, 64), ob = __shfl_xor(keyB, off, 64);
+        keyA = oa > keyA ? oa : keyA;
+        keyB = ob > keyB ? ob : keyB;
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long pi = pair0 + 2 * slot + h;
+            if (pi < n) {
+                const unsigned long long key = h ? keyB : keyA;
+                pmx_record_t rec;
+                rec.score = (int)(key >> 32);
+                rec.end_ref = 0xFFFF - (int)((key >> 16) & 0xFFFF);
+                rec.end_query = 0xFFFF - (int)(key & 0xFFFF);
+                rec.flags = rec.score > 32767 ? PMX_FLAG_SATURATED : 0;
+                out[pi] = rec;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------ host side ----
+
+template <int G, int R>
+static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
+                      pmx_record_t *d_out, hipStream_t stream)
+{
+    constexpr int QP = G * R, NP = 2 * (64 / G);
+    const int RP = ((b.max_rlen + 2 * (G - 1) + 3 + 4) / 4) * 4;
+    const size_t lds = (size_t)NP * (m.msize + 1) * QP * 2 + (size_t)NP * RP + (size_t)NP * QP +
+                       (size_t)m.msize * m.msize * 2 + 256;
+    if (lds > 160 * 1024) return 1;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_sw16_kernel<G, R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    const long long blocks = (b.n + NP - 1) / NP;
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL((pmx_sw16_kernel<G, R>), dim3((unsigned)blocks), dim3(64), lds, stream,
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
+                       m.msize, open, ext, RP, d_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
+                    pmx_record_t *d_out, hipStream_t stream, const char **kernel_name)
+{
+    if (m.msize > PMX_MAX_FAST_MSIZE) return 1;
+    if (open < 0 || ext < 0 || open > 32767 || ext > 32767) return 1;
+    if (m.max > 32767 || m.min < -32767) return 1;
+    if (b.max_rlen > 60000) return 1;                 // 16-bit column index
+    const int q = b.max_qlen;
+#define TRY(GG, RR, NAME)                                                       \
+    if (q <= (GG) * (RR)) {                                                     \
+        int rc = launch_one<GG, RR>(b, m, open, ext, d_out, stream);            \
+        if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; }       \
+    }
+    TRY(16, 10, "pmx_sw16_kernel<16,10>")
+    TRY(16, 16, "pmx_sw16_kernel<16,16>")
+    TRY(32, 16, "pmx_sw16_kernel<32,16>")
+    TRY(64, 16, "pmx_sw16_kernel<64,16>")
+    TRY(64, 32, "pmx_sw16_kernel<64,32>")
+#undef TRY
+    return 1;
+}

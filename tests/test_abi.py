@@ -1,0 +1,198 @@
+"""CPU tests of the drop-in boundary: the shared library loads, exports every symbol that
+include/parasail_amd.h declares, resolves exactly the dispatch names of the reference's name
+grammar (src/aligner/mod.rs:289-331) and implements the host-only Matrix/Profile/builder logic.
+No kernel is launched here."""
+import ctypes as C
+import itertools
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "parasail_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b((?:parasail|pmx)_[a-z0-9_]+)\s*\(", text))
+    names -= {"parasail_function_t", "parasail_pfunction_t", "parasail_pcreator_t"}
+    # macro-declared profile creators
+    for isa in ("", "_sse_128", "_avx_256", "_neon_128", "_altivec_128"):
+        for st in ("", "_stats"):
+            for w in ("sat", "8", "16", "32", "64"):
+                names.add("parasail_profile_create%s%s_%s" % (st, isa, w))
+    return {n for n in names if "##" not in n and not n.endswith("_")}
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    syms = _declared_symbols()
+    assert len(syms) > 110
+    missing = [s for s in sorted(syms) if not hasattr(pkg.lib, s)]
+    assert not missing, missing
+
+
+def test_symbols_the_reference_binds(pkg):
+    # spot list taken from the `use libparasail_sys::{...}` blocks of the reference
+    for s in ["parasail_lookup_function", "parasail_lookup_pfunction", "parasail_nw_banded", "parasail_ssw",
+              "parasail_cigar_decode", "parasail_cigar_free", "parasail_result_free", "parasail_result_get_cigar",
+              "parasail_result_get_traceback", "parasail_traceback_generic", "parasail_result_ssw_free",
+              "parasail_matrix_convert_square_to_pssm", "parasail_matrix_copy", "parasail_matrix_create",
+              "parasail_matrix_free", "parasail_matrix_from_file", "parasail_matrix_lookup",
+              "parasail_matrix_pssm_create", "parasail_matrix_set_value", "parasail_profile_free",
+              "parasail_ssw_init", "parasail_profile_create_stats_avx_256_sat", "parasail_profile_create_neon_128_64"]:
+        assert hasattr(pkg.lib, s), s
+
+
+def test_name_grammar_resolves(pkg):
+    modes = ["nw", "sw", "sg", "sg_qb", "sg_qe", "sg_qx", "sg_db", "sg_de", "sg_dx", "sg_qb_de", "sg_qe_db",
+             "sg_qb_db", "sg_qe_de", "sg_qx_db", "sg_qb_dx"]
+    outs = ["", "_trace", "_stats", "_table", "_rowcol", "_stats_table", "_stats_rowcol"]
+    n = 0
+    for m, o, v, w in itertools.product(modes, outs, ["_striped", "_scan", "_diag"], ["sat", "8", "16", "32", "64"]):
+        name = "%s%s%s_%s" % (m, o, v, w)
+        assert pkg.lib.parasail_lookup_function(name.encode()), name
+        assert not pkg.lib.parasail_lookup_pfunction(name.encode()), name
+        if v != "_diag":
+            pname = "%s%s%s_profile_%s" % (m, o, v, w)
+            assert pkg.lib.parasail_lookup_pfunction(pname.encode()), pname
+            assert not pkg.lib.parasail_lookup_function(pname.encode()), pname
+        n += 1
+    assert n == 15 * 7 * 3 * 5
+    assert pkg.lib.parasail_lookup_function(b"parasail_sw_striped_16")
+    f1 = pkg.lib.parasail_lookup_function(b"sw_striped_16")
+    f2 = pkg.lib.parasail_lookup_function(b"sw_striped_sat")
+    assert f1 != f2
+
+
+@pytest.mark.parametrize("bad", ["nw_trace_rowcol_striped_sat", "nw_striped_7", "nw_striped_", "xx_striped_sat",
+                                 "nw_blocked_sat", "nw_trace_stats_striped_sat", "nw_diag_profile_sat", "sw_striped"])
+def test_unknown_names_do_not_resolve(pkg, bad):
+    assert not pkg.lib.parasail_lookup_function(bad.encode())
+    assert not pkg.lib.parasail_lookup_pfunction(bad.encode())
+
+
+def test_builder_name_grammar_and_exclusions(pkg):
+    A = pkg.Aligner
+    assert A.new().get_parasail_fn_name() == "nw_striped_sat"                       # defaults :86-104
+    assert A.new().local().solution_width(16).get_parasail_fn_name() == "sw_striped_16"
+    assert A.new().semi_global().allow_query_gaps(["prefix", "suffix"]).allow_ref_gaps(["prefix", "suffix"]) \
+        .get_parasail_fn_name() == "sg_striped_sat"                                  # _qx_dx collapses :296-298
+    assert A.new().semi_global().allow_query_gaps(["suffix"]).allow_ref_gaps(["prefix"]) \
+        .get_parasail_fn_name() == "sg_qe_db_striped_sat"
+    assert A.new().use_trace().use_stats().get_parasail_fn_name() == "nw_stats_striped_sat"   # stats clears trace
+    assert A.new().use_stats().use_table().use_trace().get_parasail_fn_name() == "nw_trace_striped_sat"
+    assert A.new().use_table().use_last_rowcol().scan().get_parasail_fn_name() == "nw_rowcol_scan_sat"
+    with pytest.raises(pkg.PanicError):
+        A.new().use_trace().use_last_rowcol().build()                                # :243-246 + :353-358
+    with pytest.raises(pkg.PanicError):
+        A.new().solution_width(7).build()
+    # aligner_construction, tests/test_parasail.rs:48-62: null profile + use_stats builds
+    b = A.new().matrix(pkg.Matrix.default()).gap_open(10).gap_extend(1).profile(pkg.Profile.default()) \
+        .allow_query_gaps(["prefix", "suffix"]).striped().use_stats()
+    assert b.get_parasail_fn_name() == "nw_stats_striped_sat"
+    al = b.build()
+    assert (al.gap_open, al.gap_extend, al.vec_strategy) == (10, 1, "_striped")
+    # profile decides the stats slot (:301-317); profile + diag panics (:307-310)
+    m = pkg.Matrix.default()
+    p = pkg.Profile.new(b"ACGT", True, m)
+    assert A.new().profile(p).get_parasail_fn_name() == "nw_stats_striped_profile_sat"
+    p2 = pkg.Profile.new(b"ACGT", False, m)
+    assert A.new().profile(p2).use_stats().get_parasail_fn_name() == "nw_striped_profile_sat"
+    with pytest.raises(pkg.PanicError):
+        A.new().profile(p2).diag().build()
+
+
+def test_matrix_construction(pkg):
+    """tests/test_parasail.rs:5-34 (matrix_construction)"""
+    pkg.Matrix.default()
+    m = pkg.Matrix.create(b"ACGT", 3, -2)
+    m.set_value(2, 2, 100)
+    assert m.to_numpy()[2, 2] == 100
+    b = pkg.Matrix.from_name("blosum62")
+    b.to_pssm(b"ACGT")
+    sq = pkg.Matrix.from_file(os.path.join(ROOT, "tests/golden/square.txt"))
+    assert (sq.size, sq.length, sq.inner.contents.type_) == (17, 17, 0)
+    ps = pkg.Matrix.from_file(os.path.join(ROOT, "tests/golden/pssm.txt"))
+    assert (ps.length, ps.inner.contents.type_) == (10, 1)
+    assert ps.to_numpy()[2, 9] == 12 and ps.inner.contents.query == b"YSCDGCLKPI"
+    pkg.Matrix.create_pssm("abcdef", [1, 2, 3, 4, 5, 6, 7, 8], 2)
+
+
+def test_matrix_semantics(pkg, orc):
+    d = pkg.Matrix.default()
+    c = d.inner.contents
+    assert (c.size, c.length, c.type_, c.max, c.min) == (6, 6, 0, 1, -1)
+    om = orc.Matrix.default()
+    assert (d.to_numpy() == om.scores).all() and (d.mapper() == om.mapper).all()
+    with pytest.raises(pkg.NotBuiltIn):
+        pkg.Matrix.from_name("blosum62").set_value(0, 0, 1)
+    m = pkg.Matrix.create(b"ACGT", 3, -2)
+    for bad in [(-1, 0), (0, 4), (4, 0)]:
+        with pytest.raises(pkg.InvalidIndex):                 # valid range 0..=size-2, src/matrix/mod.rs:228-236
+            m.set_value(bad[0], bad[1], 1)
+    m.set_value(3, 3, 9)
+    cl = m.clone()
+    m.set_value(0, 0, -7)
+    assert cl.to_numpy()[0, 0] == 3 and cl.to_numpy()[3, 3] == 9
+    with pytest.raises(pkg.FailedLookup):
+        pkg.Matrix.from_name("nosuchmatrix")
+    with pytest.raises(pkg.FileNotFound):
+        pkg.Matrix.from_file("/nonexistent/matrix.txt")
+    with pytest.raises(pkg.PanicError):
+        pkg.Matrix.create(b"ACGT", -1, -2)
+    with pytest.raises(pkg.InteriorNulByte):
+        pkg.Matrix.create(b"AC\0T", 1, -1)
+    with pytest.raises(pkg.NotSquare):
+        pkg.Matrix.from_name("blosum62").to_pssm(b"ACGT").to_pssm(b"AC")
+
+
+def test_blosum62_matches_fixture(pkg, orc):
+    b = pkg.Matrix.from_name("blosum62")
+    f = orc.Matrix.from_file(os.path.join(ROOT, "tests/golden/blosum62.txt"))
+    assert (b.to_numpy() == f.scores).all()
+    assert (b.mapper() == f.mapper).all()
+    ff = pkg.Matrix.from_file(os.path.join(ROOT, "tests/golden/blosum62.txt"))
+    assert (ff.to_numpy() == f.scores).all() and (ff.mapper() == f.mapper).all()
+
+
+def test_profile_construction(pkg):
+    """tests/test_parasail.rs:36-45, :758-765 and src/profile/mod.rs:298-358"""
+    q = b"ATGGCACTATAA"
+    m = pkg.Matrix.default()
+    p = pkg.Profile.new(q, False, m)
+    ps = pkg.Profile.new(q, True, m)
+    assert (p.use_stats, ps.use_stats, p.query_len) == (False, True, 12)
+    with pytest.raises(pkg.QueryIsEmpty):
+        pkg.Profile.new(b"", False, m)
+    with pytest.raises(pkg.PanicError):
+        pkg.Profile.new_ssw(b"", m, 2)
+    assert pkg.Profile.new_ssw(b"ACGT", m, 2).use_stats is True
+    assert pkg.Profile.default().is_null()
+    for isa in (pkg.InstructionSet.Best, pkg.InstructionSet.SSE2, pkg.InstructionSet.SSE41, pkg.InstructionSet.AVX2,
+                pkg.InstructionSet.AltiVec, pkg.InstructionSet.Neon):
+        for w in (pkg.SolutionWidth.Sat, pkg.SolutionWidth.Bit8, pkg.SolutionWidth.Bit16, pkg.SolutionWidth.Bit32,
+                  pkg.SolutionWidth.Bit64):
+            pkg.Profile.builder(q, m).instruction_set(isa).solution_width(w).build()
+            pkg.Profile.builder(q, m).use_stats().instruction_set(isa).solution_width(w).build()
+
+
+def test_error_paths_without_gpu(pkg):
+    al = pkg.Aligner.new().build()
+    with pytest.raises(pkg.InteriorNulByte):
+        al.align(b"AC\0GT", b"ACGT")                     # src/aligner/mod.rs:399,:409
+    with pytest.raises(pkg.InteriorNulByte):
+        al.align(b"ACGT", b"A\0")
+    with pytest.raises(pkg.PanicError):
+        al.align(None, b"ACGT")                          # :403-406
+    with pytest.raises(pkg.NoBandwidth):
+        al.banded_nw(b"ACGT", b"ACGT")                   # :464-468
+    with pytest.raises(pkg.PanicError):
+        al.ssw(None, b"ACGT")                            # :512
+    cfg = pkg.pmx_config_t(5, 0, 1, 1, 0, 0, al.matrix.inner)
+    assert pkg.lib.pmx_kernel_for(C.byref(cfg), 10, 10) == b"invalid"
+    cfg = pkg.pmx_config_t(pkg.MODE_SW, 0, 5, 2, 16, 0, al.matrix.inner)
+    assert pkg.lib.pmx_kernel_for(C.byref(cfg), 150, 150) == b"pmx_sw16_kernel"
+    cfg = pkg.pmx_config_t(pkg.MODE_NW, 0, 5, 2, 16, 0, al.matrix.inner)
+    assert pkg.lib.pmx_kernel_for(C.byref(cfg), 150, 150) == b"pmx_general_kernel"

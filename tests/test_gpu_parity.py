@@ -1,0 +1,404 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X).  Everything goes through the C ABI of
+libparasail_amd.so (ctypes mirror of the parasail-rs interface) and is compared bit-for-bit with
+the CPU oracle on the same seeded inputs; the reference's own known-answer tests are replayed
+through the mirrored `Aligner` API so they read like tests/test_parasail.rs."""
+import threading
+
+import numpy as np
+import pytest
+
+from util import random_seqs, mutate, score_from_cigar, cigar_ops, DNA, AA
+
+pytestmark = pytest.mark.gpu
+
+MODES = {"nw": 0, "sg": 1, "sw": 2}
+
+
+def _builder(pkg, k):
+    b = pkg.Aligner.new()
+    {"nw": b.global_, "sg": b.semi_global, "sw": b.local}[k["mode"]]()
+    ms = k["matrix"]
+    matrix = pkg.Matrix.create(ms["alphabet"].encode(), ms["match"], ms["mismatch"])
+    b.matrix(matrix).gap_open(k["open"]).gap_extend(k["extend"]).striped()
+    if k["width"] != "sat":
+        b.solution_width(int(k["width"]))
+    if k["trace"]:
+        b.use_trace()
+    if k["stats"]:
+        b.use_stats()
+    if k["table"]:
+        b.use_table()
+    if k["rowcol"]:
+        b.use_last_rowcol()
+    if k["profile"]:
+        b.profile(pkg.Profile.new(k["query"].encode(), k["profile_stats"], matrix))
+    return b
+
+
+def test_reference_kats_through_aligner(pkg, kats):
+    """Every assertion of /root/reference/tests/test_parasail.rs, via the mirrored API."""
+    n = 0
+    for k in kats:
+        q, r = k["query"].encode(), k["ref"].encode()
+        e = k["expect"]
+        if k["mode"] == "nw_banded":
+            res = pkg.Aligner.new().bandwidth(2).build().banded_nw(q, r)
+            assert res.get_score() == e["score"] and res.is_banded()
+            n += 1
+            continue
+        if k["mode"] == "ssw":
+            res = pkg.Aligner.new().build().ssw(q, r)
+            assert (res.score(), res.query_end(), res.ref_end(), res.query_start(), res.ref_start()) == \
+                   (e["score"], e["query_end"], e["ref_end"], e["query_start"], e["ref_start"])
+            assert res.cigar_len() == 1 and res.cigar()[0] == (4 << 4) | 7
+            n += 1
+            continue
+        al = _builder(pkg, k).build()
+        res = al.align(None if k["profile"] else q, r)
+        if "score" in e: assert res.get_score() == e["score"], k["name"]
+        if "end_query" in e: assert res.get_end_query() == e["end_query"], k["name"]
+        if "end_ref" in e: assert res.get_end_ref() == e["end_ref"], k["name"]
+        if "matches" in e: assert res.get_matches() == e["matches"], k["name"]
+        if "length" in e: assert res.get_length() == e["length"], k["name"]
+        for t in ("score", "matches", "similar", "length"):
+            if t + "_table_rows" in e:
+                tab = getattr(res, "get_%s_table" % t)()
+                assert (tab.rows(), tab.cols()) == (e[t + "_table_rows"], e[t + "_table_cols"]), k["name"]
+                assert tab.get(0, 0) is not None
+            if t + "_table_last" in e:
+                assert getattr(res, "get_%s_table" % t)().last() == e[t + "_table_last"], k["name"]
+            for w in ("row", "col"):
+                key = "%s_%s" % (t, w)
+                if key in e:
+                    assert list(getattr(res, "get_" + key)()) == e[key], k["name"]
+        if "trace_table_len" in e:
+            tt = res.get_trace_table()
+            assert (tt.rows(), tt.cols(), len(tt.as_slice())) == (4, 4, 16)
+            for i in range(4):
+                for j in range(4):
+                    assert tt.get(i, j) in (0, 1, 2, 4)
+            assert res.get_cigar(q, r) == "4="
+            tb = res.get_traceback_strings(q, r)
+            assert (tb.query, tb.comparison, tb.reference) == ("ACGT", "||||", "ACGT")
+            res.print_traceback(q, r)
+        for f, v in k["flags"].items():
+            assert getattr(res, f)() == v, (k["name"], f)
+        n += 1
+    assert n == len(kats)
+
+
+def test_multithread_shared_profile(pkg):
+    """tests/test_parasail.rs:689-723"""
+    m = pkg.Matrix.default()
+    al = pkg.Aligner.new().profile(pkg.Profile.new(b"ACGT", True, m)).use_stats().striped().build()
+    out = []
+
+    def work(ref):
+        out.append(al.clone().align(None, ref).get_score())
+    th = [threading.Thread(target=work, args=(b"ACGT",)) for _ in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert out == [4, 4]
+
+
+def test_accessor_guards(pkg):
+    res = pkg.Aligner.new().build().align(b"ACGT", b"ACGT")
+    for f, exc in (("get_matches", pkg.NoStats), ("get_length", pkg.NoStats), ("get_score_table", pkg.NoTable),
+                   ("get_matches_table", pkg.NoStatsTable), ("get_score_row", pkg.NoRowCol),
+                   ("get_matches_col", pkg.NoRowCol), ("get_trace_table", pkg.NoTrace)):
+        with pytest.raises(exc):
+            getattr(res, f)()
+    with pytest.raises(pkg.NoTrace):
+        res.get_cigar(b"ACGT", b"ACGT")
+    assert res.get_similar() == 0          # no guard in the reference (src/alignment/mod.rs:87-89)
+    rc = pkg.Aligner.new().use_last_rowcol().build().align(b"ACGT", b"ACG")
+    assert list(rc.get_score_row()) == [1, 2, 3] and rc.is_rowcol() and not rc.is_stats_rowcol()
+    with pytest.raises(pkg.NoRowCol):
+        rc.get_matches_row()
+
+
+# ------------------------------------------------------------- the hot kernel (sw, int16) ----
+def _fast_case(pkg, orc, qs, rs, open_, ext, pm, om, width=16):
+    b = pkg.Aligner.new().local().matrix(pm).gap_open(open_).gap_extend(ext)
+    if width:
+        b.solution_width(width)
+    got = b.build().align_batch(qs, rs)
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    want = orc.align_batch(orc.SW, qb, qo, rb, ro, open_, ext, om)
+    bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) |
+                     (got["end_ref"] != want[:, 2]))[0]
+    assert len(bad) == 0, (bad[:5], got[bad[:5]], want[bad[:5]], [(qs[i], rs[i]) for i in bad[:2]])
+    assert (got["flags"] == 0).all()
+
+
+@pytest.mark.parametrize("gaps", [(5, 2), (0, 0), (1, 1), (11, 1), (3, 0)])
+def test_sw16_uniform_150(pkg, orc, gaps):
+    rng = np.random.default_rng(1000 + gaps[0])
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 2001, 150, 150)
+    rs = [mutate(rng, q)[:150].ljust(150, b"A") if i % 2 else random_seqs(rng, 1, 150, 150)[0]
+          for i, q in enumerate(qs)]
+    _fast_case(pkg, orc, qs, rs, gaps[0], gaps[1], pm, om)
+
+
+def test_sw16_ragged_lengths(pkg, orc):
+    rng = np.random.default_rng(1100)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 1500, 1, 160)
+    rs = [mutate(rng, q, 0.1, 0.05) if rng.random() < 0.5 else random_seqs(rng, 1, 1, 300)[0] for q in qs]
+    _fast_case(pkg, orc, qs, rs, 5, 2, pm, om)
+    _fast_case(pkg, orc, qs[:1], rs[:1], 5, 2, pm, om)          # n = 1
+    _fast_case(pkg, orc, [b"A"], [b"C"], 5, 2, pm, om)          # all-zero table -> (0, 0, 0)
+    _fast_case(pkg, orc, [b"A"] * 3, [b"A"] * 3, 0, 0, pm, om)
+
+
+def test_sw16_default_matrix_and_lowercase(pkg, orc):
+    rng = np.random.default_rng(1200)
+    qs = random_seqs(rng, 400, 5, 150)
+    rs = [mutate(rng, q).lower() if i % 3 == 0 else mutate(rng, q) for i, q in enumerate(qs)]
+    qs = [q + b"N" if i % 5 == 0 else q for i, q in enumerate(qs)]      # wildcard symbol
+    _fast_case(pkg, orc, qs, rs, 0, 0, pkg.Matrix.default(), orc.Matrix.default(), width=0)   # sw_striped_sat
+    _fast_case(pkg, orc, qs, rs, 2, 1, pkg.Matrix.default(), orc.Matrix.default())
+
+
+@pytest.mark.parametrize("maxlen", [160, 256, 512, 1000, 2000])
+def test_sw16_blosum62_all_instantiations(pkg, orc, maxlen):
+    """one batch per (G,R) instantiation of the fast kernel"""
+    rng = np.random.default_rng(1300 + maxlen)
+    pm = pkg.Matrix.from_name("blosum62")
+    om = orc.Matrix.from_file("tests/golden/blosum62.txt")
+    n = 120 if maxlen <= 512 else 40
+    qs = random_seqs(rng, n, max(1, maxlen // 3), maxlen, AA)
+    qs[0] = random_seqs(rng, 1, maxlen, maxlen, AA)[0]
+    rs = [mutate(rng, q, 0.3, 0.05, AA) if rng.random() < 0.7 else random_seqs(rng, 1, 10, maxlen, AA)[0] for q in qs]
+    _fast_case(pkg, orc, qs, rs, 11, 1, pm, om)
+
+
+def test_sw16_file_matrix_asymmetric(pkg, orc):
+    """scores[q][r] orientation: make the matrix asymmetric with set_value"""
+    rng = np.random.default_rng(1400)
+    pm = pkg.Matrix.create(b"ACGT", 2, -3)
+    pm.set_value(0, 1, 4)       # query A vs reference C
+    om = orc.Matrix.create("ACGT", 2, -3)
+    om.scores[0, 1] = 4
+    qs = random_seqs(rng, 300, 20, 150)
+    rs = random_seqs(rng, 300, 20, 150)
+    _fast_case(pkg, orc, qs, rs, 5, 2, pm, om)
+
+
+def test_sw16_saturation_flag_and_promotion(pkg, orc):
+    pm, om = pkg.Matrix.create(b"ACGT", 40, -40), orc.Matrix.create("ACGT", 40, -40)
+    q = b"ACGT" * 250
+    fixed = pkg.Aligner.new().local().matrix(pm).gap_open(5).gap_extend(2).solution_width(16).build()
+    got = fixed.align_batch([q, b"ACGT"], [q, b"ACGT"])
+    assert got["flags"][0] & pkg.FLAG_SATURATED and not got["flags"][1]
+    assert got["score"][1] == 160
+    one = fixed.align(q, q)
+    assert one.is_saturated()
+    assert orc.align(orc.SW, q, q, 5, 2, om, bits=16).saturated == 1
+    sat = pkg.Aligner.new().local().matrix(pm).gap_open(5).gap_extend(2).build()     # sw_striped_sat
+    one = sat.align(q, q)
+    assert not one.is_saturated() and one.get_score() == 40000
+
+
+# --------------------------------------------------------------------- general kernel ----
+def _check_general(pkg, orc, mode, sg, q, r, open_, ext, pm, om, width=0):
+    want = orc.align(mode, q, r, open_, ext, om, sg_flags=sg if sg is not None else orc.SG_ALL, bits=width,
+                     stats=True, table=True, rowcol=True, trace=True)
+
+    def mk():
+        b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext)
+        [b.global_, b.semi_global, b.local][mode]()
+        if width:
+            b.solution_width(width)
+        if mode == 1 and sg is not None:
+            qg = [n for f, n in ((orc.S1_BEG, "prefix"), (orc.S1_END, "suffix")) if sg & f]
+            dg = [n for f, n in ((orc.S2_BEG, "prefix"), (orc.S2_END, "suffix")) if sg & f]
+            b.allow_query_gaps(qg).allow_ref_gaps(dg)
+        return b
+    plain = mk().build().align(q, r)
+    assert (plain.get_score(), plain.get_end_query(), plain.get_end_ref()) == \
+           (want.score, want.end_query, want.end_ref), (mode, sg, q, r)
+    assert plain.is_saturated() == bool(want.saturated)
+    st = mk().use_stats().use_table().build().align(q, r)
+    assert (st.get_score(), st.get_matches(), st.get_similar(), st.get_length()) == \
+           (want.score, want.matches, want.similar, want.length), (mode, sg, q, r)
+    for t in ("score", "matches", "similar", "length"):
+        got = np.asarray(getattr(st, "get_%s_table" % t)().as_slice()).reshape(len(q), len(r))
+        assert (got == getattr(want, t + "_table")).all(), (t, mode, q, r)
+    rc = mk().use_stats().use_last_rowcol().build().align(q, r)
+    for t in ("score", "matches", "similar", "length"):
+        assert (np.asarray(getattr(rc, "get_%s_row" % t)()) == getattr(want, t + "_row")).all(), (t, mode)
+        assert (np.asarray(getattr(rc, "get_%s_col" % t)()) == getattr(want, t + "_col")).all(), (t, mode)
+    tr = mk().use_trace().build().align(q, r)
+    got = np.asarray(tr.get_trace_table().as_slice()).reshape(len(q), len(r))
+    assert (got == want.trace_table).all(), (mode, q, r)
+    assert tr.get_cigar(q, r) == orc.cigar(want)
+    tb = tr.get_traceback_strings(q, r)
+    assert (tb.query, tb.comparison, tb.reference) == orc.traceback_strings(want)
+    return want, tr
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_general_all_outputs_small(pkg, orc, mode):
+    rng = np.random.default_rng(2000 + mode)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    for it in range(12):
+        q = random_seqs(rng, 1, 1, 90)[0]
+        r = mutate(rng, q, 0.15, 0.08) if it % 2 else random_seqs(rng, 1, 1, 90)[0]
+        gaps = [(5, 2), (0, 0), (1, 1), (11, 1)][it % 4]
+        want, tr = _check_general(pkg, orc, mode, None, q, r, gaps[0], gaps[1], pm, om)
+        if mode != 1:
+            bq, br = tr.get_cigar_begin(q, r)
+            s, i, j = score_from_cigar(tr.get_cigar(q, r), q, r, bq, br, om.scores, om.mapper, *gaps)
+            assert s == want.score
+
+
+def test_general_multi_band_protein(pkg, orc):
+    """queries longer than one 64-row band, BLOSUM62 11/1 (BASELINE config 1 style)"""
+    rng = np.random.default_rng(2100)
+    pm = pkg.Matrix.from_name("blosum62")
+    om = orc.Matrix.from_file("tests/golden/blosum62.txt")
+    for ql in (64, 65, 128, 129, 200):
+        q = random_seqs(rng, 1, ql, ql, AA)[0]
+        r = mutate(rng, q, 0.3, 0.05, AA)
+        for mode in (0, 1, 2):
+            _check_general(pkg, orc, mode, None, q, r, 11, 1, pm, om)
+
+
+def test_general_sg_variants(pkg, orc):
+    rng = np.random.default_rng(2200)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    for sg in (orc.S1_BEG, orc.S1_END, orc.S2_BEG, orc.S2_END, orc.S1_BEG | orc.S1_END, orc.S2_BEG | orc.S2_END,
+               orc.S1_BEG | orc.S2_END, orc.S1_END | orc.S2_BEG, orc.S1_BEG | orc.S2_BEG, orc.S1_END | orc.S2_END):
+        for _ in range(3):
+            q = random_seqs(rng, 1, 5, 80)[0]
+            core = mutate(rng, q, 0.1, 0.05)
+            r = random_seqs(rng, 1, 0, 20)[0] + core + random_seqs(rng, 1, 0, 20)[0] if rng.random() < 0.5 else core[3:-3] or core
+            _check_general(pkg, orc, 1, sg, q, r, 5, 2, pm, om)
+
+
+def test_general_fixed_width_saturation(pkg, orc):
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    q = b"ACGT" * 40
+    for mode in (0, 1, 2):
+        w8 = orc.align(mode, q, q, 5, 2, om, bits=8)
+        assert w8.saturated == 1
+        b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).solution_width(8)
+        [b.global_, b.semi_global, b.local][mode]()
+        assert b.build().align(q, q).is_saturated()
+    # negative overflow in nw: long unrelated sequences at 8 bit
+    rng = np.random.default_rng(2300)
+    q, r = random_seqs(rng, 1, 60, 60)[0], random_seqs(rng, 1, 5, 5)[0]
+    want = orc.align(0, q, r, 5, 2, om, bits=8)
+    got = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).solution_width(8).build().align(q, r)
+    assert got.is_saturated() == bool(want.saturated) and want.saturated == 1
+
+
+def test_general_batch_modes_and_stats(pkg, orc):
+    rng = np.random.default_rng(2400)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 200, 1, 200)
+    rs = [mutate(rng, q, 0.1, 0.05) for q in qs]
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    for mode in (0, 1, 2):
+        b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).use_stats()
+        [b.global_, b.semi_global, b.local][mode]()
+        rec, st = b.build().align_batch(qs, rs)
+        want = orc.align_batch(mode, qb, qo, rb, ro, 5, 2, om)
+        assert (rec["score"] == want[:, 0]).all() and (rec["end_query"] == want[:, 1]).all() \
+            and (rec["end_ref"] == want[:, 2]).all()
+        for k in range(0, 200, 17):
+            w = orc.align(mode, qs[k], rs[k], 5, 2, om, stats=True)
+            assert (st["matches"][k], st["similar"][k], st["length"][k]) == (w.matches, w.similar, w.length)
+
+
+def test_profile_batch_nw_stats_blosum62(pkg, orc):
+    """BASELINE config 3 shape, reduced: one reused protein query, global + stats"""
+    rng = np.random.default_rng(2500)
+    pm = pkg.Matrix.from_name("blosum62")
+    om = orc.Matrix.from_file("tests/golden/blosum62.txt")
+    q = random_seqs(rng, 1, 300, 300, AA)[0]
+    rs = [mutate(rng, q, 0.4, 0.05, AA) + random_seqs(rng, 1, 0, 200, AA)[0] for _ in range(60)]
+    prof = pkg.Profile.new(q, True, pm)
+    al = pkg.Aligner.new().profile(prof).matrix(pm).gap_open(11).gap_extend(1).solution_width(16).build()
+    assert al.fn_name == "nw_stats_striped_profile_16"
+    rec, st = al.align_batch([], rs)
+    for k, r in enumerate(rs):
+        w = orc.align(0, q, r, 11, 1, om, stats=True, bits=16)
+        assert (rec["score"][k], rec["end_query"][k], rec["end_ref"][k]) == (w.score, w.end_query, w.end_ref)
+        assert (st["matches"][k], st["similar"][k], st["length"][k]) == (w.matches, w.similar, w.length)
+        assert bool(rec["flags"][k] & 1) == bool(w.saturated)
+    one = al.align(None, rs[0])
+    assert one.get_score() == rec["score"][0] and one.get_matches() == st["matches"][0]
+
+
+def test_batch_cigar_semi_global(pkg, orc):
+    """BASELINE config 4 shape, reduced: sg + traceback + CIGAR, walk done on the device"""
+    rng = np.random.default_rng(2600)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 150, 200, 250)
+    rs = [mutate(rng, q, 0.1, 0.02) for q in qs]
+    for mode in (1, 0, 2):
+        b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).solution_width(16).use_trace()
+        [b.global_, b.semi_global, b.local][mode]()
+        rec, cig = b.build().align_batch_cigar(qs, rs)
+        for k in range(len(qs)):
+            w = orc.align(mode, qs[k], rs[k], 5, 2, om, trace=True)
+            assert (rec["score"][k], rec["end_query"][k], rec["end_ref"][k]) == (w.score, w.end_query, w.end_ref)
+            assert cig[k] == orc.cigar(w), (mode, k)
+
+
+def test_pssm_single_pair(pkg, orc):
+    pm = pkg.Matrix.from_name("blosum62")
+    om = orc.Matrix.from_file("tests/golden/blosum62.txt")
+    q, r = b"MKVLAAGIVGL", b"MKVIAGGLVGL"
+    ps = pm.to_pssm(q)
+    got = pkg.Aligner.new().matrix(ps).gap_open(11).gap_extend(1).build().align(q, r)
+    assert got.get_score() == orc.align(0, q, r, 11, 1, om).score
+
+
+def test_banded_matches_full_when_band_is_wide(pkg, orc):
+    rng = np.random.default_rng(2700)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    for _ in range(10):
+        q = random_seqs(rng, 1, 20, 150)[0]
+        r = mutate(rng, q, 0.1, 0.03)
+        full = orc.align(0, q, r, 5, 2, om).score
+        wide = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).bandwidth(400).build().banded_nw(q, r)
+        assert wide.get_score() == full and wide.is_banded() and wide.is_global()
+        narrow = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).bandwidth(20).build().banded_nw(q, r)
+        assert narrow.get_score() <= full
+
+
+# ------------------------------------------------------------------ full-size properties ----
+def test_headline_config_properties(pkg, orc):
+    """BASELINE config 2 at full size (1M x 150 x 150): sampled oracle parity plus
+    size-independent properties (self alignment, order invariance, checksum stability)."""
+    import bench
+    n = 1_000_000
+    qbuf, qoff, rbuf, roff = bench.make_cfg2_inputs(n)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    al = pkg.Aligner.new().local().matrix(pm).gap_open(5).gap_extend(2).solution_width(16).build()
+    got = al.align_batch_packed(qbuf, qoff, rbuf, roff)
+    assert (got["flags"] == 0).all() and got["score"].min() >= 0 and got["score"].max() <= 300
+    assert (got["end_query"] < 150).all() and (got["end_ref"] < 150).all()
+    rng = np.random.default_rng(5)
+    idx = np.sort(rng.choice(n, size=3000, replace=False))
+    sq = [qbuf[qoff[i]:qoff[i + 1]].tobytes() for i in idx]
+    sr = [rbuf[roff[i]:roff[i + 1]].tobytes() for i in idx]
+    b1, o1 = orc.pack(sq); b2, o2 = orc.pack(sr)
+    want = orc.align_batch(orc.SW, b1, o1, b2, o2, 5, 2, om)
+    assert (got["score"][idx] == want[:, 0]).all()
+    assert (got["end_query"][idx] == want[:, 1]).all() and (got["end_ref"][idx] == want[:, 2]).all()
+    # self alignment: score 2*L, ends L-1
+    selfa = al.align_batch_packed(qbuf[:150 * 4096], qoff[:4097], qbuf[:150 * 4096], qoff[:4097])
+    assert (selfa["score"] == 300).all() and (selfa["end_query"] == 149).all() and (selfa["end_ref"] == 149).all()
+    # order invariance: reversing the batch reverses the records
+    m = 8191
+    rev_q = qbuf[:150 * m].reshape(m, 150)[::-1].copy().reshape(-1)
+    rev_r = rbuf[:150 * m].reshape(m, 150)[::-1].copy().reshape(-1)
+    rev = al.align_batch_packed(rev_q, qoff[:m + 1], rev_r, roff[:m + 1])
+    assert (rev[::-1] == got[:m]).all()
+    # deterministic
+    again = al.align_batch_packed(qbuf, qoff, rbuf, roff)
+    assert (again == got).all()
