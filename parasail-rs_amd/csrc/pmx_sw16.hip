@@ -193,7 +193,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 #pragma unroll
         for (int k = 0; k < R; ++k) Hsave[k] = PK((m & I32(Hprev[k])) | (~m & I32(Hsave[k])));
         best = nb;
-        jj += 0x00010001;
+        jj = __builtin_bit_cast(int, __builtin_bit_cast(v2u, jj) + one2);   // per-half add: no carry into pair B
     }
 
     // ---- per lane: first row of the saved strip that holds the best ---------------------

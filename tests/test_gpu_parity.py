@@ -288,7 +288,7 @@ def test_general_fixed_width_saturation(pkg, orc):
         assert b.build().align(q, q).is_saturated()
     # negative overflow in nw: long unrelated sequences at 8 bit
     rng = np.random.default_rng(2300)
-    q, r = random_seqs(rng, 1, 60, 60)[0], random_seqs(rng, 1, 5, 5)[0]
+    q, r = random_seqs(rng, 1, 80, 80)[0], random_seqs(rng, 1, 5, 5)[0]
     want = orc.align(0, q, r, 5, 2, om, bits=8)
     got = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).solution_width(8).build().align(q, r)
     assert got.is_saturated() == bool(want.saturated) and want.saturated == 1
