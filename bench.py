@@ -29,9 +29,11 @@ SEED = 20260001
 MATCH, MISMATCH, OPEN, EXT = 2, -3, 5, 2
 ALGO_BYTES_PER_PAIR = LEN + LEN + 12          # 312 B / pair
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# VALU ceiling for the packed-int16 kernel (DESIGN.md "Roofline"): 256 CU x 4 SIMD x 32 lanes x
-# 2.4 GHz lane-instructions/s, 2 cells per v_pk_* instruction, 11 packed instructions per cell pair.
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9
+# VALU ceiling for the packed-int16 kernel (DESIGN.md "Roofline"): measured on this chip
+# (profiles/r01/valu_rate_microbench.txt) every VOP3P/VOP3 instruction (v_pk_*_i16, v_perm, v_bfi)
+# issues at one wave64 instruction per 4 cycles per SIMD; 1024 SIMDs x 2.4 GHz / 4.  One such
+# instruction updates 2 cells in each of 64 lanes; the kernel needs 11 of them per cell pair.
+VOP3P_INSTR_PER_S = 256 * 4 * 2.4e9 / 4.0
 PK_OPS_PER_CELL_PAIR = 11.0
 
 
@@ -45,16 +47,50 @@ def make_cfg2_inputs(n=N_PAIRS, seed=SEED):
     return q, off, r, off.copy()
 
 
-def cpu_baseline(qbuf, qoff, rbuf, roff):
-    """The CPU port of the reference's kernel class (Farrar striped int16, AVX2 + OpenMP), all host
-    cores, on a bounded sample of the same workload."""
-    from oracle import oracle as orc
-    m = orc.Matrix.create("ACGT", MATCH, MISMATCH)
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    cores = min(cores, max(1, q // per))
+        except Exception:
+            pass
+    return cores
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/<round>/*pmc_summary.json: FETCH_SIZE and WRITE_SIZE in KiB, separate passes).
+    gfx950 correction from MI355X_MICROARCH.md: FETCH_SIZE counts half of the fetched bytes."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return int((2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+    except Exception:
+        return None
+
+
+def cpu_baseline(qbuf, qoff, rbuf, roff):
+    """The CPU port of the reference's kernel class (Farrar striped int16, AVX2 + OpenMP), all host
+    cores, on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    m = orc.Matrix.create("ACGT", MATCH, MISMATCH)
+    cores = usable_cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
 
     def run(npairs):
@@ -65,7 +101,7 @@ def cpu_baseline(qbuf, qoff, rbuf, roff):
     run(2048)                                           # warm-up (thread pool, page-in)
     t, used, _ = run(16384)
     rate = 16384 / max(t, 1e-6)
-    sample = int(min(N_PAIRS, max(16384, rate * 3.0)))  # about 3 s of wall on all cores
+    sample = int(min(N_PAIRS, max(16384, rate * 2.0)))  # ~2 s wall
     t, used, out = run(sample)
     return {"value": round(sample * LEN * LEN / t / 1e9, 3), "unit": "GCUPS", "cores": int(used), "kind": "port",
             "sample": "%d of the same 150x150 pairs, striped int16 AVX2 + OpenMP (oracle/pmx_striped_cpu.c), "
@@ -174,7 +210,7 @@ def main():
 
     if rank == 0:
         achieved = ALGO_BYTES_PER_PAIR * n / (kern_ms * 1e-3) / 1e9
-        valu_peak_gcups = VALU_LANE_OPS * 2.0 / PK_OPS_PER_CELL_PAIR / 1e9
+        valu_peak_gcups = VOP3P_INSTR_PER_S * 128.0 / PK_OPS_PER_CELL_PAIR / 1e9
         kern_gcups = cells_per_rank_step / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "GCUPS (cell updates/s) local-affine SW, 1M 150x150 pairs, 1/2/4/8 GPUs",
@@ -186,12 +222,13 @@ def main():
                        "pairs_per_gpu": n, "kernel": kernel, "inputs": "resident in HBM",
                        "exchange": "none" if world == 1 else "RCCL gather of 16-B records to rank 0, overlapped"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic_bytes() if n == N_PAIRS else None,
                          "kernel_ms": round(kern_ms, 4),
                          "note": "312 algorithmic B/pair; the path is VALU-bound, see roofline_valu"},
             "roofline_valu": {"bound": "valu", "achieved": round(kern_gcups, 2), "peak": round(valu_peak_gcups, 1),
                               "unit": "GCUPS", "frac": round(kern_gcups / valu_peak_gcups, 4),
-                              "model": "11 v_pk_*_i16 per 2 cells, 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"},
+                              "model": "11 VOP3P instr per 128 cells; measured issue rate 1 VOP3P wave64 instr / 4 cycles / SIMD, "
+                                       "1024 SIMDs, 2.4 GHz"},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_out = cpu_baseline(qbuf, qoff, rbuf, roff)

@@ -77,12 +77,13 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     const int lane = threadIdx.x;
     const int g = lane % G;
     const int slot = lane / G;
-    const int MS1 = msize + 1;           // + pad symbol row
-    const int PROF_STRIDE = MS1 * QP * 2;   // bytes per pair
+    const int PROF_STRIDE = msize * QP * 2;   // bytes per pair
 
-    // LDS carve: [prof NP][rsym NP*RP][qsym NP*QP][mat msize*msize*2][map 256]
+    // LDS carve: [prof NP][shared pad row QP*2][rsym NP*RP][qsym NP*QP][mat msize*msize*2][map 256]
+    // The pad row sits right behind the last pair's profile; pair p reaches it with the symbol
+    // value (NP - p) * msize, so no per-pair copy is needed.
     int16_t *prof = reinterpret_cast<int16_t *>(lds);
-    unsigned char *rsym = lds + NP * PROF_STRIDE;
+    unsigned char *rsym = lds + NP * PROF_STRIDE + QP * 2;
     unsigned char *qsym = rsym + NP * RP;
     int16_t *mat = reinterpret_cast<int16_t *>(qsym + NP * QP);
     unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
@@ -105,7 +106,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
             qsym[p * QP + i] = (i < ql) ? map[qbuf[qb + i]] : (unsigned char)0xFF;
         for (int j = lane; j < RP; j += 64) {
             const int jj = j - (G - 1);
-            rsym[p * RP + j] = (jj >= 0 && jj < rl) ? map[rbuf[rb + jj]] : (unsigned char)msize;
+            rsym[p * RP + j] = (jj >= 0 && jj < rl) ? map[rbuf[rb + jj]] : (unsigned char)((NP - p) * msize);
         }
     }
     __syncthreads();
@@ -114,19 +115,16 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     for (int p = 0; p < NP; ++p) {
         int *pp = reinterpret_cast<int *>(prof) + p * (PROF_STRIDE / 4);
         const unsigned char *qs = qsym + p * QP;
-        for (int idx = lane; idx < MS1 * QP2; idx += 64) {
+        for (int idx = lane; idx < msize * QP2; idx += 64) {
             const int sym = idx / QP2, rp = idx - sym * QP2;
-            int v;
-            if (sym == msize) v = FLOOR2;
-            else {
-                const int q0 = qs[2 * rp], q1 = qs[2 * rp + 1];
-                const int s0 = (q0 == 0xFF) ? 0 : mat[q0 * msize + sym];
-                const int s1 = (q1 == 0xFF) ? 0 : mat[q1 * msize + sym];
-                v = (s0 & 0xFFFF) | (s1 << 16);
-            }
-            pp[idx] = v;
+            const int q0 = qs[2 * rp], q1 = qs[2 * rp + 1];
+            const int s0 = (q0 == 0xFF) ? 0 : mat[q0 * msize + sym];
+            const int s1 = (q1 == 0xFF) ? 0 : mat[q1 * msize + sym];
+            pp[idx] = (s0 & 0xFFFF) | (s1 << 16);
         }
     }
+    for (int idx = lane; idx < QP2; idx += 64)
+        reinterpret_cast<int *>(prof)[NP * (PROF_STRIDE / 4) + idx] = FLOOR2;
     __syncthreads();
 
     // ---- systolic sweep ---------------------------------------------------------------
@@ -140,60 +138,73 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     const v2s vOpen = PK((open & 0xFFFF) | (open << 16));
     const v2s vExt = PK((ext & 0xFFFF) | (ext << 16));
     const v2s vFloor = PK(FLOOR2);
+    typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+    const v2u one2 = {1, 1}, zero2 = {0, 0};
 
-    v2s Hprev[R], E[R], Hsave[R];
+    // Two copies of the H strip: a step reads one and writes the other, so the loop-carried
+    // values never have to be moved between registers.
+    v2s HA[R], HB[R], E[R], Hsave[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) { Hprev[k] = vFloor; E[k] = vFloor; Hsave[k] = vFloor; }
+    for (int k = 0; k < R; ++k) { HA[k] = vFloor; HB[k] = vFloor; E[k] = vFloor; Hsave[k] = vFloor; }
     v2s best = vFloor;
     int bestcol = 0;
     int jj = ((-g) & 0xFFFF) * 0x00010001;    // packed column index of this lane
     int Hout = FLOOR2, Fout = FLOOR2;         // last-row H and outgoing F of the previous step
     v2s diag0 = vFloor;                       // H(i0-1, j-1)
 
-    const int T = max_rlen + G - 1;
-    for (int t = 0; t < T; ++t) {
-        const int symA = rsA[t], symB = rsB[t];
+    auto load_scores = [&](int symA, int symB, int (&wa)[R / 2], int (&wb)[R / 2]) {
         const int *sa = reinterpret_cast<const int *>(profA + symA * SYMSTRIDE);
         const int *sb = reinterpret_cast<const int *>(profB + symB * SYMSTRIDE);
-        int wa[R / 2], wb[R / 2];
 #pragma unroll
         for (int k = 0; k < R / 2; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
-
+    };
+    auto step = [&](const v2s (&Hold)[R], v2s (&Hnew)[R], const int (&wa)[R / 2], const int (&wb)[R / 2]) {
         const int Hin = group_shift_up<G>(Hout, FLOOR2, g);   // H(i0-1, j)
         v2s F = PK(group_shift_up<G>(Fout, FLOOR2, g));       // F(i0, j)
-        v2s diag = diag0;
-        diag0 = PK(Hin);
         v2s colmax = vFloor;
-        v2s H;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const int w0 = wa[k / 2], w1 = wb[k / 2];
-            const v2s s = PK(__builtin_amdgcn_perm(w1, w0, (k & 1) ? 0x07060302 : 0x05040100));
-            H = pk_adds(diag, s);
+            const v2s s = PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
+            v2s H = pk_adds(k == 0 ? diag0 : Hold[k - 1], s);
             H = pk_max(H, E[k]);
             H = pk_max(H, F);
             const v2s Ho = pk_subs(H, vOpen);
             E[k] = pk_max(pk_subs(E[k], vExt), Ho);
             F = pk_max(pk_subs(F, vExt), Ho);
-            diag = Hprev[k];
-            Hprev[k] = H;
+            Hnew[k] = H;
             colmax = pk_max(colmax, H);
         }
-        Hout = I32(H);
+        diag0 = PK(Hin);
+        Hout = I32(Hnew[R - 1]);
         Fout = I32(F);
-
         // end-position bookkeeping: strictly greater than the lane's best so far?
         const v2s nb = pk_max(best, colmax);
         const int x = I32(nb) ^ I32(best);
-        typedef unsigned short v2u __attribute__((ext_vector_type(2)));
-        const v2u one2 = {1, 1}, zero2 = {0, 0};
-        const v2u xm = zero2 - __builtin_elementwise_min(__builtin_bit_cast(v2u, x), one2);
-        const int m = __builtin_bit_cast(int, xm);        // 0xFFFF in every improved half
-        bestcol = (m & jj) | (~m & bestcol);
+        const int m = __builtin_bit_cast(int, zero2 - __builtin_elementwise_min(__builtin_bit_cast(v2u, x), one2));
+        // m = 0xFFFF in every improved half; v_bfi_b32 d = (m & a) | (~m & b)
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bestcol) : "v"(m), "v"(jj), "v"(bestcol));
 #pragma unroll
-        for (int k = 0; k < R; ++k) Hsave[k] = PK((m & I32(Hprev[k])) | (~m & I32(Hsave[k])));
+        for (int k = 0; k < R; ++k) {
+            int hs;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hs) : "v"(m), "v"(I32(Hnew[k])), "v"(I32(Hsave[k])));
+            Hsave[k] = PK(hs);
+        }
         best = nb;
         jj = __builtin_bit_cast(int, __builtin_bit_cast(v2u, jj) + one2);   // per-half add: no carry into pair B
+    };
+
+    // software pipeline: scores of step t+1 are fetched from LDS while step t computes
+    const int T = (max_rlen + G - 1 + 1) & ~1;           // even number of steps (extra pad column is harmless)
+    int w0a[R / 2], w0b[R / 2], w1a[R / 2], w1b[R / 2];
+    load_scores(rsA[0], rsB[0], w0a, w0b);
+    int nsA = rsA[1], nsB = rsB[1];
+    for (int t = 0; t < T; t += 2) {
+        load_scores(nsA, nsB, w1a, w1b);
+        nsA = rsA[t + 2]; nsB = rsB[t + 2];
+        step(HA, HB, w0a, w0b);
+        load_scores(nsA, nsB, w0a, w0b);
+        nsA = rsA[t + 3]; nsB = rsB[t + 3];
+        step(HB, HA, w1a, w1b);
     }
 
     // ---- per lane: first row of the saved strip that holds the best ---------------------
@@ -242,8 +253,9 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
                       pmx_record_t *d_out, hipStream_t stream)
 {
     constexpr int QP = G * R, NP = 2 * (64 / G);
-    const int RP = ((b.max_rlen + 2 * (G - 1) + 3 + 4) / 4) * 4;
-    const size_t lds = (size_t)NP * (m.msize + 1) * QP * 2 + (size_t)NP * RP + (size_t)NP * QP +
+    if (NP * m.msize > 255) return 1;                 // per-pair pad symbol must fit a byte
+    const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
+    const size_t lds = (size_t)NP * m.msize * QP * 2 + (size_t)QP * 2 + (size_t)NP * RP + (size_t)NP * QP +
                        (size_t)m.msize * m.msize * 2 + 256;
     if (lds > 160 * 1024) return 1;
     static bool attr_done = false;   // per instantiation
