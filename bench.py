@@ -131,12 +131,20 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PMX_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share
+    # devices, records are gathered through host memory); the driver's runs use nccl (= RCCL).
+    backend = os.environ.get("PMX_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     n = args.pairs
     qbuf, qoff, rbuf, roff = make_cfg2_inputs(n, SEED + rank)     # each rank its own batch (weak scaling)
@@ -158,6 +166,9 @@ def main():
     def step(k, events=None):
         out = d_out[k % 2]
         stream = torch.cuda.current_stream(dev)
+        while len(pending) >= 2:          # the gather that last read this output buffer must be done
+            fin, work = pending.pop(0)
+            work.wait()
         if events is not None:
             events[0].record(stream)
         pkg.align_batch_device(cfg, n, d_q.data_ptr(), d_qo.data_ptr(), d_r.data_ptr(), d_ro.data_ptr(),
@@ -166,14 +177,14 @@ def main():
             events[1].record(stream)
         if world > 1:
             # exchange step: records of this step go to rank 0 while the next step computes
-            done = torch.cuda.Event()
-            done.record(stream)
-            while len(pending) >= 2:
-                fin, work = pending.pop(0)
-                work.wait()
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(done)
-                pending.append(sharding.gather_records(out, counts, dst=0, async_op=True))
+            if backend == "nccl":
+                done = torch.cuda.Event()
+                done.record(stream)
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(done)
+                    pending.append(sharding.gather_records(out, counts, dst=0, async_op=True))
+            else:
+                pending.append(sharding.gather_records(out.cpu(), counts, dst=0, async_op=True))
 
     def drain():
         while pending:
@@ -220,7 +231,8 @@ def main():
             "config": {"workload": "cfg2: %d pairs/GPU x (150 bp x 150 bp) i.i.d. DNA, sw_striped_16 (score + end "
                                    "positions), Matrix::create(ACGT,2,-3), gaps 5/2" % n,
                        "pairs_per_gpu": n, "kernel": kernel, "inputs": "resident in HBM",
-                       "exchange": "none" if world == 1 else "RCCL gather of 16-B records to rank 0, overlapped"},
+                       "exchange": "none" if world == 1 else "%s gather of 16-B records to rank 0, overlapped" %
+                                   ("RCCL" if backend == "nccl" else backend)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic_bytes() if n == N_PAIRS else None,
                          "kernel_ms": round(kern_ms, 4),

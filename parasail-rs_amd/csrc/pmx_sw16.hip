@@ -30,6 +30,7 @@
 // profile row is -32768 (H falls to zero, gaps only decay), padded query rows score 0; neither
 // can strictly exceed the true maximum nor precede its first occurrence in column-major order.
 #include "pmx_common.h"
+#include <cstdlib>
 
 typedef short v2s __attribute__((ext_vector_type(2)));
 
@@ -287,6 +288,7 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
         int rc = launch_one<GG, RR>(b, m, open, ext, d_out, stream);            \
         if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; }       \
     }
+    if (getenv("PMX_SW16_G8")) { TRY(8, 20, "pmx_sw16_kernel<8,20>") }
     TRY(16, 10, "pmx_sw16_kernel<16,10>")
     TRY(16, 16, "pmx_sw16_kernel<16,16>")
     TRY(32, 16, "pmx_sw16_kernel<32,16>")

@@ -1,0 +1,64 @@
+"""Worker for tests/test_dist.py: world_size ranks over gloo on CPU.  Exercises the N>1 path of
+the product -- the shard plan and the gather of result records (parasail-rs_amd/sharding.py) --
+with the CPU oracle standing in for the GPU kernel (there is no GPU in the CPU test tier)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as g                       # noqa: E402
+from util import random_seqs, mutate              # noqa: E402
+
+
+def main():
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    g.load_pkg()
+    from importlib import import_module
+    sharding = import_module("parasail_rs_amd.sharding")
+    orc = g.load_oracle()
+    om = orc.Matrix.create("ACGT", 2, -3)
+
+    rng = np.random.default_rng(99)               # same inputs on every rank
+    qs = random_seqs(rng, 301, 20, 200)
+    rs = [mutate(rng, q, 0.1, 0.05) if i % 3 else random_seqs(rng, 1, 20, 600)[0] for i, q in enumerate(qs)]
+    ql, rl = [len(x) for x in qs], [len(x) for x in rs]
+
+    for plan in ("cells", "uniform"):
+        bounds = sharding.shard_bounds_by_cells(ql, rl, world) if plan == "cells" \
+            else sharding.shard_bounds_uniform(len(qs), world)
+        assert bounds[0] == 0 and bounds[-1] == len(qs) and all(a <= b for a, b in zip(bounds, bounds[1:]))
+        lo, hi = bounds[rank], bounds[rank + 1]
+        qb, qo = orc.pack(qs[lo:hi]); rb, ro = orc.pack(rs[lo:hi])
+        local = orc.align_batch(orc.SW, qb, qo, rb, ro, 5, 2, om)
+        rec = torch.from_numpy(np.concatenate([local, np.zeros((hi - lo, 1), np.int32)], axis=1))
+        counts = [bounds[k + 1] - bounds[k] for k in range(world)]
+        for async_op in (False, True):
+            out, work = sharding.gather_records(rec, counts, dst=0, async_op=async_op)
+            if async_op:
+                work.wait()
+                out = out()
+            if rank == 0:
+                qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+                want = orc.align_batch(orc.SW, qb, qo, rb, ro, 5, 2, om)
+                assert out.shape == (len(qs), 4)
+                assert (out[:, :3].numpy() == want).all(), plan
+            else:
+                assert out is None
+        if plan == "cells" and world > 1:
+            cells = np.array(ql, dtype=np.int64) * np.array(rl, dtype=np.int64)
+            per = [int(cells[bounds[k]:bounds[k + 1]].sum()) for k in range(world)]
+            assert max(per) - min(per) <= 2 * int(cells.max()), per      # balanced to within two pairs
+    dist.barrier()
+    if rank == 0:
+        print("dist ok world=%d" % world)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
