@@ -855,7 +855,7 @@ static int check_cfg(const pmx_config_t *cfg)
 
 static bool fast_sw_eligible(const pmx_config_t *cfg)
 {
-    return cfg->mode == PMX_MODE_SW && cfg->want == 0 && (cfg->width == 0 || cfg->width == 16) &&
+    return cfg->mode == PMX_MODE_SW && cfg->want == 0 && cfg->width != 8 &&
            cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE;
 }
 
@@ -900,8 +900,34 @@ extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
     PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, max_qlen, max_rlen};
     if (fast_sw_eligible(cfg)) {
         const int rc = pmx_launch_sw16(b, dm.d, cfg->open, cfg->extend, d_out, st, nullptr);
-        if (rc == 0) return 0;
         if (rc < 0) { set_err("sw16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
+        if (rc == 0) {
+            // Overflow promotion (`sat`, 32, 64): pairs whose int16 lanes overflowed are re-run in the
+            // 32-bit kernel.  Skipped without any synchronisation when no score can reach 32768.
+            const long long bound_score = (long long)(max_qlen < max_rlen ? max_qlen : max_rlen) *
+                                          (cfg->matrix->max > 0 ? cfg->matrix->max : 0);
+            if (cfg->width == 16 || bound_score <= 32767) return 0;
+            DevBuf<int64_t> list; DevBuf<int> cnt;
+            list.alloc((size_t)n); cnt.alloc(1);
+            int rc2 = pmx_launch_collect_saturated(d_out, n, list.p, cnt.p, st);
+            if (rc2) { set_err("collect kernel failed (%d)", rc2); return rc2; }
+            int count = 0;
+            HIP_OR_RET(hipMemcpyAsync(&count, cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_OR_RET(hipStreamSynchronize(st));
+            if (count == 0) return 0;
+            DevBuf<int32_t> bnd;
+            const size_t stride2 = (size_t)8 * max_rlen;
+            bnd.alloc((size_t)count * stride2);
+            PmxGeneralArgs a; memset(&a, 0, sizeof a);
+            a.qbuf = d_qbuf; a.qoff = d_qoff; a.rbuf = d_rbuf; a.roff = d_roff; a.n = count; a.index = list.p;
+            a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
+            a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
+            a.bits = 32; a.bound = bnd.p; a.bound_stride = (long long)stride2; a.rec = d_out;
+            rc2 = pmx_launch_general(a, false, st);
+            if (rc2) { set_err("promotion launch failed (%d)", rc2); return rc2 < 0 ? rc2 : -1; }
+            HIP_OR_RET(hipStreamSynchronize(st));      // scratch is released on return
+            return 0;
+        }
         // rc == 1: shape not covered by the fast kernel -> general kernel below
     }
     if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }

@@ -34,6 +34,7 @@ struct PmxGeneralArgs {
     const uint8_t *qbuf; const int64_t *qoff;     // qoff == nullptr: one shared query of shared_qlen bytes at qbuf
     const uint8_t *rbuf; const int64_t *roff;
     long long n;
+    const int64_t *index;     // optional: block b works on pair index[b] (promotion re-runs); n = number of blocks
     int shared_qlen;
     const int16_t *scores; const uint8_t *mapper; int msize;
     int mat_rows;             // rows of `scores`: msize for a square matrix, query length for a PSSM
@@ -66,3 +67,6 @@ struct PmxWalkArgs {
     uint32_t *ops; const int64_t *ops_off; int32_t *nops; int32_t *beg; /* 2 per pair */
 };
 int pmx_launch_walk(const PmxWalkArgs &a, hipStream_t stream);
+
+// Collect the indices of records flagged PMX_FLAG_SATURATED: list[0..*count) (device), any order.
+int pmx_launch_collect_saturated(const pmx_record_t *rec, long long n, int64_t *list, int *count, hipStream_t stream);

@@ -64,7 +64,7 @@ void pmx_general_kernel(const PmxGeneralArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     int16_t *mat = reinterpret_cast<int16_t *>(lds);
     const int lane = threadIdx.x;
-    const long long pair = blockIdx.x;
+    const long long pair = a.index ? a.index[blockIdx.x] : (long long)blockIdx.x;
     const int msize = a.msize;
 
     for (int i = lane; i < a.mat_rows * msize; i += 64) mat[i] = a.scores[i];
@@ -76,9 +76,9 @@ void pmx_general_kernel(const PmxGeneralArgs a)
     rb = a.roff[pair]; rl = (int)(a.roff[pair + 1] - rb);
     const uint8_t *q = a.qbuf + qb, *r = a.rbuf + rb;
     const long long tab0 = a.tab_off ? a.tab_off[pair] : 0;
-    const long long row0 = (a.n > 1) ? rb : 0;     // row outputs packed like the references
+    const long long row0 = (a.n > 1 || a.index) ? rb : 0;     // row outputs packed like the references
     const long long col0 = (a.n > 1 && a.qoff) ? qb : (a.qoff ? 0 : pair * (long long)ql);
-    volatile int32_t *bound = a.bound + pair * a.bound_stride;
+    volatile int32_t *bound = a.bound + (long long)blockIdx.x * a.bound_stride;
 
     const int mode = a.mode, open = a.open, ext = a.ext, band_w = a.band;
     const bool s1_beg = mode == PMX_MODE_SG && (a.sg_flags & PMX_SG_QB);
@@ -330,5 +330,21 @@ int pmx_launch_walk(const PmxWalkArgs &a, hipStream_t stream)
     const unsigned blocks = (unsigned)((a.n + 63) / 64);
     hipLaunchKernelGGL(pmx_walk_kernel, dim3(blocks), dim3(64), 0, stream, a);
     hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+__global__ void pmx_collect_saturated_kernel(const pmx_record_t *rec, long long n, int64_t *list, int *count)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (rec[i].flags & PMX_FLAG_SATURATED)) list[atomicAdd(count, 1)] = i;
+}
+
+int pmx_launch_collect_saturated(const pmx_record_t *rec, long long n, int64_t *list, int *count, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int), stream);
+    if (e != hipSuccess) return -(int)e;
+    hipLaunchKernelGGL(pmx_collect_saturated_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, n, list, count);
+    e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
