@@ -897,7 +897,7 @@ extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
     DevMat dm;
     if (get_devmat(cfg->matrix, &dm)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, max_qlen, max_rlen};
+    PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, max_qlen, max_rlen, 0};
     if (fast_sw_eligible(cfg)) {
         const int rc = pmx_launch_sw16(b, dm.d, cfg->open, cfg->extend, d_out, st, nullptr);
         if (rc < 0) { set_err("sw16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }

@@ -20,6 +20,7 @@ struct PmxBatch {
     const uint8_t *rbuf; const int64_t *roff;
     int64_t n;
     int max_qlen, max_rlen;
+    int q_shared;            // > 0: one shared query of that many bytes at qbuf (profile arm), qoff unused
 };
 
 // Fast path: local alignment, score + end positions, packed int16 lanes.

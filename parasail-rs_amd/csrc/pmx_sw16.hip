@@ -66,6 +66,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                      const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
                      long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
                      int msize, int open, int ext, int RP /* rsym stride, bytes */,
+                     int q_shared /* > 0: every pair uses qbuf[0..q_shared) */,
                      pmx_record_t *__restrict__ out)
 {
     static_assert(R % 2 == 0, "rows are stored two per dword");
@@ -80,48 +81,56 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     const int slot = lane / G;
     const int PROF_STRIDE = msize * QP * 2;   // bytes per pair
 
-    // LDS carve: [prof NP][shared pad row QP*2][rsym NP*RP][qsym NP*QP][mat msize*msize*2][map 256]
+    // LDS carve: [prof NP][shared pad row QP*2][rsym NP*RP][mat msize*msize*2][map 256][pair table NP*4 ints]
     // The pad row sits right behind the last pair's profile; pair p reaches it with the symbol
     // value (NP - p) * msize, so no per-pair copy is needed.
     int16_t *prof = reinterpret_cast<int16_t *>(lds);
     unsigned char *rsym = lds + NP * PROF_STRIDE + QP * 2;
-    unsigned char *qsym = rsym + NP * RP;
-    int16_t *mat = reinterpret_cast<int16_t *>(qsym + NP * QP);
+    int16_t *mat = reinterpret_cast<int16_t *>(rsym + NP * RP);
     unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
+    int *ptab = reinterpret_cast<int *>(map + 256 + ((4 - ((msize * msize * 2) & 3)) & 3));
 
     const long long pair0 = (long long)blockIdx.x * NP;
 
-    // ---- stage matrix + mapper -------------------------------------------------------
+    // ---- stage matrix, mapper and the per-pair (offset, length) table -------------------
     for (int i = lane; i < msize * msize; i += 64) mat[i] = gmat[i];
     for (int i = lane; i < 256; i += 64) map[i] = gmap[i];
-    __syncthreads();
-
-    // ---- sequences -> symbols ---------------------------------------------------------
-    int max_rlen = 0;
-    for (int p = 0; p < NP; ++p) {
-        long long pi = pair0 + p; if (pi >= n) pi = n - 1;
-        const long long qb = qoff[pi], rb = roff[pi];
-        const int ql = (int)(qoff[pi + 1] - qb), rl = (int)(roff[pi + 1] - rb);
-        max_rlen = rl > max_rlen ? rl : max_rlen;
-        for (int i = lane; i < QP; i += 64)
-            qsym[p * QP + i] = (i < ql) ? map[qbuf[qb + i]] : (unsigned char)0xFF;
-        for (int j = lane; j < RP; j += 64) {
-            const int jj = j - (G - 1);
-            rsym[p * RP + j] = (jj >= 0 && jj < rl) ? map[rbuf[rb + jj]] : (unsigned char)((NP - p) * msize);
-        }
+    if (lane < NP) {
+        long long pi = pair0 + lane; if (pi >= n) pi = n - 1;
+        const long long qb = q_shared ? 0 : qoff[pi], rb = roff[pi];
+        ptab[4 * lane + 0] = (int)(qb - (q_shared ? 0 : qoff[pair0]));      // offsets relative to the block's first pair
+        ptab[4 * lane + 1] = q_shared ? q_shared : (int)(qoff[pi + 1] - qb);
+        ptab[4 * lane + 2] = (int)(rb - roff[pair0]);
+        ptab[4 * lane + 3] = (int)(roff[pi + 1] - rb);
     }
     __syncthreads();
+    const uint8_t *qbase = qbuf + (q_shared ? 0 : qoff[pair0]);
+    const uint8_t *rbase = rbuf + roff[pair0];
 
-    // ---- query profiles ---------------------------------------------------------------
-    for (int p = 0; p < NP; ++p) {
-        int *pp = reinterpret_cast<int *>(prof) + p * (PROF_STRIDE / 4);
-        const unsigned char *qs = qsym + p * QP;
-        for (int idx = lane; idx < msize * QP2; idx += 64) {
-            const int sym = idx / QP2, rp = idx - sym * QP2;
-            const int q0 = qs[2 * rp], q1 = qs[2 * rp + 1];
-            const int s0 = (q0 == 0xFF) ? 0 : mat[q0 * msize + sym];
-            const int s1 = (q1 == 0xFF) ? 0 : mat[q1 * msize + sym];
-            pp[idx] = (s0 & 0xFFFF) | (s1 << 16);
+    // ---- reference symbols (with G-1 pad symbols on both sides) -------------------------
+    int max_rlen = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) max_rlen = max(max_rlen, ptab[4 * p + 3]);
+    for (int item = lane; item < NP * RP; item += 64) {
+        const int p = item / RP, j = item - p * RP;
+        const int jj = j - (G - 1);
+        const int rl = ptab[4 * p + 3];
+        rsym[item] = (jj >= 0 && jj < rl) ? map[rbase[ptab[4 * p + 2] + jj]] : (unsigned char)((NP - p) * msize);
+    }
+
+    // ---- query profiles: one (pair, row pair) item per lane and iteration -----------------
+    for (int item = lane; item < NP * QP2; item += 64) {
+        const int p = item / QP2, rp = item - p * QP2;
+        const int ql = ptab[4 * p + 1];
+        const uint8_t *qp = qbase + ptab[4 * p + 0];
+        const int i0 = 2 * rp, i1 = 2 * rp + 1;
+        const int q0 = (i0 < ql) ? map[qp[i0]] : -1;
+        const int q1 = (i1 < ql) ? map[qp[i1]] : -1;
+        int *pp = reinterpret_cast<int *>(prof) + p * (PROF_STRIDE / 4) + rp;
+        for (int sym = 0; sym < msize; ++sym) {
+            const int s0 = (q0 < 0) ? 0 : mat[q0 * msize + sym];
+            const int s1 = (q1 < 0) ? 0 : mat[q1 * msize + sym];
+            pp[sym * QP2] = (s0 & 0xFFFF) | (s1 << 16);
         }
     }
     for (int idx = lane; idx < QP2; idx += 64)
@@ -140,7 +149,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     const v2s vExt = PK((ext & 0xFFFF) | (ext << 16));
     const v2s vFloor = PK(FLOOR2);
     typedef unsigned short v2u __attribute__((ext_vector_type(2)));
-    const v2u one2 = {1, 1}, zero2 = {0, 0};
+    const v2u one2 = {1, 1};
 
     // Two copies of the H strip: a step reads one and writes the other, so the loop-carried
     // values never have to be moved between registers.
@@ -180,9 +189,13 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         Fout = I32(F);
         // end-position bookkeeping: strictly greater than the lane's best so far?
         const v2s nb = pk_max(best, colmax);
-        const int x = I32(nb) ^ I32(best);
-        const int m = __builtin_bit_cast(int, zero2 - __builtin_elementwise_min(__builtin_bit_cast(v2u, x), one2));
-        // m = 0xFFFF in every improved half; v_bfi_b32 d = (m & a) | (~m & b)
+        int m;   // 0xFFFF in every half whose column maximum strictly exceeds the best so far
+        {
+            const v2s d = pk_subs(best, colmax);            // negative exactly where colmax > best
+            const v2s sh = {15, 15};
+            m = I32(d >> sh);                               // v_pk_ashrrev_i16
+        }
+        // v_bfi_b32 d = (m & a) | (~m & b)
         asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bestcol) : "v"(m), "v"(jj), "v"(bestcol));
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -256,8 +269,8 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
     constexpr int QP = G * R, NP = 2 * (64 / G);
     if (NP * m.msize > 255) return 1;                 // per-pair pad symbol must fit a byte
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
-    const size_t lds = (size_t)NP * m.msize * QP * 2 + (size_t)QP * 2 + (size_t)NP * RP + (size_t)NP * QP +
-                       (size_t)m.msize * m.msize * 2 + 256;
+    const size_t lds = (size_t)NP * m.msize * QP * 2 + (size_t)QP * 2 + (size_t)NP * RP +
+                       (size_t)m.msize * m.msize * 2 + 256 + 4 + (size_t)NP * 16;
     if (lds > 160 * 1024) return 1;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
@@ -270,7 +283,7 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
     if (blocks <= 0) return 0;
     hipLaunchKernelGGL((pmx_sw16_kernel<G, R>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
-                       m.msize, open, ext, RP, d_out);
+                       m.msize, open, ext, RP, b.q_shared, d_out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
