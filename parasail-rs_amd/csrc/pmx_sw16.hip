@@ -111,26 +111,56 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     int max_rlen = 0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) max_rlen = max(max_rlen, ptab[4 * p + 3]);
-    for (int item = lane; item < NP * RP; item += 64) {
-        const int p = item / RP, j = item - p * RP;
-        const int jj = j - (G - 1);
-        const int rl = ptab[4 * p + 3];
-        rsym[item] = (jj >= 0 && jj < rl) ? map[rbase[ptab[4 * p + 2] + jj]] : (unsigned char)((NP - p) * msize);
+    // Global loads are issued in batches of UB independent loads per lane before anything consumes
+    // them: the prologue is latency-bound otherwise (one HBM/L2 round trip per loop iteration).
+    constexpr int UB = 8;
+    for (int item0 = 0; item0 < NP * RP; item0 += 64 * UB) {
+        unsigned char raw[UB]; int pad[UB]; bool ok[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int item = item0 + u * 64 + lane;
+            const int p = min(item / RP, NP - 1), j = item - p * RP;
+            const int jj = j - (G - 1);
+            ok[u] = item < NP * RP && jj >= 0 && jj < ptab[4 * p + 3];
+            pad[u] = (NP - p) * msize;
+            raw[u] = ok[u] ? rbase[ptab[4 * p + 2] + jj] : (unsigned char)0;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int item = item0 + u * 64 + lane;
+            if (item < NP * RP) rsym[item] = ok[u] ? map[raw[u]] : (unsigned char)pad[u];
+        }
     }
 
     // ---- query profiles: one (pair, row pair) item per lane and iteration -----------------
-    for (int item = lane; item < NP * QP2; item += 64) {
-        const int p = item / QP2, rp = item - p * QP2;
-        const int ql = ptab[4 * p + 1];
-        const uint8_t *qp = qbase + ptab[4 * p + 0];
-        const int i0 = 2 * rp, i1 = 2 * rp + 1;
-        const int q0 = (i0 < ql) ? map[qp[i0]] : -1;
-        const int q1 = (i1 < ql) ? map[qp[i1]] : -1;
-        int *pp = reinterpret_cast<int *>(prof) + p * (PROF_STRIDE / 4) + rp;
-        for (int sym = 0; sym < msize; ++sym) {
-            const int s0 = (q0 < 0) ? 0 : mat[q0 * msize + sym];
-            const int s1 = (q1 < 0) ? 0 : mat[q1 * msize + sym];
-            pp[sym * QP2] = (s0 & 0xFFFF) | (s1 << 16);
+    constexpr int QITEMS = (NP * QP2 + 63) / 64;          // items per lane (compile time)
+    constexpr int QB = QITEMS < 5 ? QITEMS : 5;
+    for (int it0 = 0; it0 < QITEMS; it0 += QB) {
+        unsigned char r0[QB], r1[QB]; bool v0[QB], v1[QB];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const int item = (it0 + u) * 64 + lane;
+            const int p = min(item / QP2, NP - 1), rp = item - p * QP2;
+            const int ql = ptab[4 * p + 1];
+            const uint8_t *qp = qbase + ptab[4 * p + 0];
+            v0[u] = item < NP * QP2 && 2 * rp < ql; v1[u] = item < NP * QP2 && 2 * rp + 1 < ql;
+            r0[u] = v0[u] ? qp[2 * rp] : (unsigned char)0;
+            r1[u] = v1[u] ? qp[2 * rp + 1] : (unsigned char)0;
+        }
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const int item = (it0 + u) * 64 + lane;
+            if (it0 + u < QITEMS && item < NP * QP2) {
+                const int p = item / QP2, rp = item - p * QP2;
+                const int q0 = v0[u] ? map[r0[u]] : -1;
+                const int q1 = v1[u] ? map[r1[u]] : -1;
+                int *pp = reinterpret_cast<int *>(prof) + p * (PROF_STRIDE / 4) + rp;
+                for (int sym = 0; sym < msize; ++sym) {
+                    const int s0 = (q0 < 0) ? 0 : mat[q0 * msize + sym];
+                    const int s1 = (q1 < 0) ? 0 : mat[q1 * msize + sym];
+                    pp[sym * QP2] = (s0 & 0xFFFF) | (s1 << 16);
+                }
+            }
         }
     }
     for (int idx = lane; idx < QP2; idx += 64)
