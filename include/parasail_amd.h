@@ -226,6 +226,7 @@ void parasail_profile_free(parasail_profile_t *profile);
 #define PMX_WANT_CIGAR 2     /* on-device traceback, CIGAR text per pair */
 
 #define PMX_FLAG_SATURATED 1 /* result record flag: the requested width overflowed */
+#define PMX_FLAG_RERUN 2     /* internal: a fast kernel left its exact range; never visible to callers */
 
 typedef struct pmx_config {
     int mode;                /* PMX_MODE_* */

@@ -906,10 +906,13 @@ extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
             // 32-bit kernel.  Skipped without any synchronisation when no score can reach 32768.
             const long long bound_score = (long long)(max_qlen < max_rlen ? max_qlen : max_rlen) *
                                           (cfg->matrix->max > 0 ? cfg->matrix->max : 0);
-            if (cfg->width == 16 || bound_score <= 32767) return 0;
+            // (the max3 variant of the fast kernel is exact up to 29 696 - max score; beyond that it sets
+            //  PMX_FLAG_RERUN and the pair is redone here whatever the requested width)
+            if (bound_score <= 27000) return 0;
+            const int mask = PMX_FLAG_RERUN | (cfg->width == 16 ? 0 : PMX_FLAG_SATURATED);
             DevBuf<int64_t> list; DevBuf<int> cnt;
             list.alloc((size_t)n); cnt.alloc(1);
-            int rc2 = pmx_launch_collect_saturated(d_out, n, list.p, cnt.p, st);
+            int rc2 = pmx_launch_collect_saturated(d_out, n, list.p, cnt.p, mask, st);
             if (rc2) { set_err("collect kernel failed (%d)", rc2); return rc2; }
             int count = 0;
             HIP_OR_RET(hipMemcpyAsync(&count, cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -922,7 +925,7 @@ extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
             a.qbuf = d_qbuf; a.qoff = d_qoff; a.rbuf = d_rbuf; a.roff = d_roff; a.n = count; a.index = list.p;
             a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
             a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
-            a.bits = 32; a.bound = bnd.p; a.bound_stride = (long long)stride2; a.rec = d_out;
+            a.bits = cfg->width == 16 ? 16 : 32; a.bound = bnd.p; a.bound_stride = (long long)stride2; a.rec = d_out;
             rc2 = pmx_launch_general(a, false, st);
             if (rc2) { set_err("promotion launch failed (%d)", rc2); return rc2 < 0 ? rc2 : -1; }
             HIP_OR_RET(hipStreamSynchronize(st));      // scratch is released on return

@@ -69,5 +69,5 @@ struct PmxWalkArgs {
 };
 int pmx_launch_walk(const PmxWalkArgs &a, hipStream_t stream);
 
-// Collect the indices of records flagged PMX_FLAG_SATURATED: list[0..*count) (device), any order.
-int pmx_launch_collect_saturated(const pmx_record_t *rec, long long n, int64_t *list, int *count, hipStream_t stream);
+// Collect the indices of records whose flags intersect `mask`: list[0..*count) (device), any order.
+int pmx_launch_collect_saturated(const pmx_record_t *rec, long long n, int64_t *list, int *count, int mask, hipStream_t stream);

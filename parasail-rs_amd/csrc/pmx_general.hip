@@ -333,18 +333,18 @@ int pmx_launch_walk(const PmxWalkArgs &a, hipStream_t stream)
     return e == hipSuccess ? 0 : -(int)e;
 }
 
-__global__ void pmx_collect_saturated_kernel(const pmx_record_t *rec, long long n, int64_t *list, int *count)
+__global__ void pmx_collect_saturated_kernel(const pmx_record_t *rec, long long n, int64_t *list, int *count, int mask)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && (rec[i].flags & PMX_FLAG_SATURATED)) list[atomicAdd(count, 1)] = i;
+    if (i < n && (rec[i].flags & mask)) list[atomicAdd(count, 1)] = i;
 }
 
-int pmx_launch_collect_saturated(const pmx_record_t *rec, long long n, int64_t *list, int *count, hipStream_t stream)
+int pmx_launch_collect_saturated(const pmx_record_t *rec, long long n, int64_t *list, int *count, int mask, hipStream_t stream)
 {
     if (n <= 0) return 0;
     hipError_t e = hipMemsetAsync(count, 0, sizeof(int), stream);
     if (e != hipSuccess) return -(int)e;
-    hipLaunchKernelGGL(pmx_collect_saturated_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, n, list, count);
+    hipLaunchKernelGGL(pmx_collect_saturated_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, n, list, count, mask);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

@@ -58,15 +58,31 @@ __device__ __forceinline__ int group_shift_up(int x, int neutral, int g)
 }
 
 #define NEG16 ((short)-32768)
+#define M3_BIAS 2048
+#define M3_BIAS2 ((M3_BIAS << 16) | M3_BIAS)
+#define M3_LIMIT(maxs) (31744 - ((maxs) > 0 ? (maxs) : 0))     // a best at or above this may have left the exact range
+
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s pk_subus(v2s a, v2s b)      // v_pk_sub_u16 clamp: saturates at 0
+{
+    return __builtin_bit_cast(v2s, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, b)));
+}
+__device__ __forceinline__ v2s pk_max3f(v2s a, v2s b, v2s c)   // integer max3 on {0} U [1024, 31743] patterns
+{
+    int r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(__builtin_bit_cast(int, a)), "v"(__builtin_bit_cast(int, b)), "v"(__builtin_bit_cast(int, c)));
+    return __builtin_bit_cast(v2s, r);
+}
 #define FLOOR2 0x80008000   // both halves = -32768 = "zero" of the offset domain
 
-template <int G, int R>
+template <int G, int R, bool M3>
 __global__ __launch_bounds__(64)
 void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                      const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
                      long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
                      int msize, int open, int ext, int RP /* rsym stride, bytes */,
                      int q_shared /* > 0: every pair uses qbuf[0..q_shared) */,
+                     int limit /* M3 only: biased scores at or above this are flagged for a re-run */,
                      pmx_record_t *__restrict__ out)
 {
     static_assert(R % 2 == 0, "rows are stored two per dword");
@@ -177,20 +193,22 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 
     const v2s vOpen = PK((open & 0xFFFF) | (open << 16));
     const v2s vExt = PK((ext & 0xFFFF) | (ext << 16));
-    const v2s vFloor = PK(FLOOR2);
     typedef unsigned short v2u __attribute__((ext_vector_type(2)));
     const v2u one2 = {1, 1};
+    // "zero" of the value domain: -32768 for the saturating-int16 variant, BIAS for the max3 variant
+    constexpr int ZERO2 = M3 ? M3_BIAS2 : FLOOR2;
+    const v2s vZero = PK(ZERO2);
 
     // Two copies of the H strip: a step reads one and writes the other, so the loop-carried
     // values never have to be moved between registers.
     v2s HA[R], HB[R], E[R], Hsave[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) { HA[k] = vFloor; HB[k] = vFloor; E[k] = vFloor; Hsave[k] = vFloor; }
-    v2s best = vFloor;
+    for (int k = 0; k < R; ++k) { HA[k] = vZero; HB[k] = vZero; E[k] = M3 ? PK(0) : vZero; Hsave[k] = vZero; }
+    v2s best = vZero;
     int bestcol = 0;
     int jj = ((-g) & 0xFFFF) * 0x00010001;    // packed column index of this lane
-    int Hout = FLOOR2, Fout = FLOOR2;         // last-row H and outgoing F of the previous step
-    v2s diag0 = vFloor;                       // H(i0-1, j-1)
+    int Hout = ZERO2, Fout = ZERO2;           // last-row H and outgoing F of the previous step
+    v2s diag0 = vZero;                        // H(i0-1, j-1)
 
     auto load_scores = [&](int symA, int symB, int (&wa)[R / 2], int (&wb)[R / 2]) {
         const int *sa = reinterpret_cast<const int *>(profA + symA * SYMSTRIDE);
@@ -199,31 +217,47 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         for (int k = 0; k < R / 2; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
     };
     auto step = [&](const v2s (&Hold)[R], v2s (&Hnew)[R], const int (&wa)[R / 2], const int (&wb)[R / 2]) {
-        const int Hin = group_shift_up<G>(Hout, FLOOR2, g);   // H(i0-1, j)
-        v2s F = PK(group_shift_up<G>(Fout, FLOOR2, g));       // F(i0, j)
-        v2s colmax = vFloor;
+        const int Hin = group_shift_up<G>(Hout, ZERO2, g);    // H(i0-1, j)
+        v2s F = PK(group_shift_up<G>(Fout, ZERO2, g));        // F(i0, j)
+        v2s colmax = vZero;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const v2s s = PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
-            v2s H = pk_adds(k == 0 ? diag0 : Hold[k - 1], s);
-            H = pk_max(H, E[k]);
-            H = pk_max(H, F);
-            const v2s Ho = pk_subs(H, vOpen);
-            E[k] = pk_max(pk_subs(E[k], vExt), Ho);
-            F = pk_max(pk_subs(F, vExt), Ho);
-            Hnew[k] = H;
-            colmax = pk_max(colmax, H);
+            const v2s d = (k == 0) ? diag0 : Hold[k - 1];
+            v2s H;
+            if (M3) {
+                // Biased unsigned lanes: every live value is 0 or in [1024, 31743], where the bit
+                // patterns of non-negative f16 order like integers, so v_pk_maximum3_f16 is an exact
+                // integer max3 (profiles/microbench/max3_f16_int.hip).  A pad score of -32768 sets the
+                // sign bit: a negative f16 that loses against everything.
+                const v2s Tt = PK(I32(__builtin_bit_cast(v2u, d) + __builtin_bit_cast(v2u, s)));
+                H = pk_max3f(Tt, E[k], F);
+                const v2s Ho = pk_subus(H, vOpen);
+                E[k] = pk_max3f(pk_subus(E[k], vExt), Ho, Ho);
+                F = pk_max3f(pk_subus(F, vExt), Ho, vZero);
+                Hnew[k] = H;
+                if (k & 1) colmax = pk_max3f(colmax, Hnew[k - 1], H);
+            } else {
+                H = pk_adds(d, s);
+                H = pk_max(H, E[k]);
+                H = pk_max(H, F);
+                const v2s Ho = pk_subs(H, vOpen);
+                E[k] = pk_max(pk_subs(E[k], vExt), Ho);
+                F = pk_max(pk_subs(F, vExt), Ho);
+                Hnew[k] = H;
+                colmax = pk_max(colmax, H);
+            }
         }
         diag0 = PK(Hin);
         Hout = I32(Hnew[R - 1]);
         Fout = I32(F);
         // end-position bookkeeping: strictly greater than the lane's best so far?
-        const v2s nb = pk_max(best, colmax);
+        const v2s nb = M3 ? pk_max3f(best, colmax, colmax) : pk_max(best, colmax);
         int m;   // 0xFFFF in every half whose column maximum strictly exceeds the best so far
         {
-            const v2s d = pk_subs(best, colmax);            // negative exactly where colmax > best
+            const v2s dd = M3 ? (best - colmax) : pk_subs(best, colmax);   // negative exactly where colmax > best
             const v2s sh = {15, 15};
-            m = I32(d >> sh);                               // v_pk_ashrrev_i16
+            m = I32(dd >> sh);                              // v_pk_ashrrev_i16
         }
         // v_bfi_b32 d = (m & a) | (~m & b)
         asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bestcol) : "v"(m), "v"(jj), "v"(bestcol));
@@ -261,7 +295,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
             if ((short)(I32(Hsave[k]) & 0xFFFF) == bA) kA = k;
             if ((short)(I32(Hsave[k]) >> 16) == bB) kB = k;
         }
-        const unsigned sA = (unsigned)(bA + 32768), sB = (unsigned)(bB + 32768);
+        const unsigned sA = (unsigned)(bA - (M3 ? M3_BIAS : -32768)), sB = (unsigned)(bB - (M3 ? M3_BIAS : -32768));
         const unsigned cA = bestcol & 0xFFFF, cB = (unsigned)bestcol >> 16;
         const unsigned rA = g * R + kA, rB = g * R + kB;
         keyA = ((unsigned long long)sA << 32) | ((0xFFFFu - cA) << 16) | (0xFFFFu - rA);
@@ -283,7 +317,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 rec.score = (int)(key >> 32);
                 rec.end_ref = 0xFFFF - (int)((key >> 16) & 0xFFFF);
                 rec.end_query = 0xFFFF - (int)(key & 0xFFFF);
-                rec.flags = rec.score > 32767 ? PMX_FLAG_SATURATED : 0;
+                if (M3) rec.flags = (rec.score + M3_BIAS >= limit) ? PMX_FLAG_RERUN : 0;   // left the exact range: redo in 32 bits
+                else rec.flags = rec.score > 32767 ? PMX_FLAG_SATURATED : 0;
                 out[pi] = rec;
             }
         }
@@ -292,7 +327,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 
 // ------------------------------------------------------------------------ host side ----
 
-template <int G, int R>
+template <int G, int R, bool M3>
 static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                       pmx_record_t *d_out, hipStream_t stream)
 {
@@ -304,16 +339,16 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
     if (lds > 160 * 1024) return 1;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_sw16_kernel<G, R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_sw16_kernel<G, R, M3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL((pmx_sw16_kernel<G, R>), dim3((unsigned)blocks), dim3(64), lds, stream,
+    hipLaunchKernelGGL((pmx_sw16_kernel<G, R, M3>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
-                       m.msize, open, ext, RP, b.q_shared, d_out);
+                       m.msize, open, ext, RP, b.q_shared, M3_LIMIT(m.max), d_out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
@@ -326,12 +361,14 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
     if (m.max > 32767 || m.min < -32767) return 1;
     if (b.max_rlen > 60000) return 1;                 // 16-bit column index
     const int q = b.max_qlen;
+    // max3 variant: gap penalties and the most negative score must keep every live value >= 1024
+    const bool m3 = !getenv("PMX_SW16_NO_M3") && open <= 1024 && ext <= 1024 && m.min >= -1024 && m.max <= 2048;
 #define TRY(GG, RR, NAME)                                                       \
     if (q <= (GG) * (RR)) {                                                     \
-        int rc = launch_one<GG, RR>(b, m, open, ext, d_out, stream);            \
-        if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; }       \
+        int rc = m3 ? launch_one<GG, RR, true>(b, m, open, ext, d_out, stream)  \
+                    : launch_one<GG, RR, false>(b, m, open, ext, d_out, stream);\
+        if (rc <= 0) { if (kernel_name) *kernel_name = m3 ? NAME "/max3" : NAME; return rc; }       \
     }
-    if (getenv("PMX_SW16_G8")) { TRY(8, 20, "pmx_sw16_kernel<8,20>") }
     TRY(16, 10, "pmx_sw16_kernel<16,10>")
     TRY(16, 16, "pmx_sw16_kernel<16,16>")
     TRY(32, 16, "pmx_sw16_kernel<32,16>")
