@@ -29,12 +29,12 @@ SEED = 20260001
 MATCH, MISMATCH, OPEN, EXT = 2, -3, 5, 2
 ALGO_BYTES_PER_PAIR = LEN + LEN + 12          # 312 B / pair
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# VALU ceiling for the packed-int16 kernel (DESIGN.md "Roofline"): measured on this chip
-# (profiles/r01/valu_rate_microbench.txt) every VOP3P/VOP3 instruction (v_pk_*_i16, v_perm, v_bfi)
-# issues at one wave64 instruction per 4 cycles per SIMD; 1024 SIMDs x 2.4 GHz / 4.  One such
-# instruction updates 2 cells in each of 64 lanes; the kernel needs 11 of them per cell pair.
-VOP3P_INSTR_PER_S = 256 * 4 * 2.4e9 / 4.0
-PK_OPS_PER_CELL_PAIR = 11.0
+# VALU ceiling for the hot kernel (DESIGN.md "Roofline").  Measured issue rates on this chip
+# (profiles/r01/valu_rate_microbench.txt): a VOP3/VOP3P wave64 instruction (v_pk_maximum3_f16,
+# v_perm_b32, v_bfi_b32) takes 4 cycles of its SIMD, a 32-bit-encoded VOP2 (v_add_u32, v_sub_u32)
+# 2 cycles.  Per 2 cells x 64 lanes the max3+vop2 variant issues 5.5 VOP3 + 4 VOP2 = 30 cycles.
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
+CYCLES_PER_128_CELLS = 5.5 * 4 + 4 * 2
 
 
 def make_cfg2_inputs(n=N_PAIRS, seed=SEED):
@@ -155,7 +155,7 @@ def main():
     d_out = [torch.zeros((n, 4), dtype=torch.int32, device=dev) for _ in range(2)]
     matrix = pkg.Matrix.create(b"ACGT", MATCH, MISMATCH)
     cfg = pkg.pmx_config_t(pkg.MODE_SW, 0, OPEN, EXT, 16, 0, matrix.inner)
-    kernel = pkg.lib.pmx_kernel_for(C.byref(cfg), LEN, LEN).decode()
+    kernel = pkg.lib.pmx_kernel_for(C.byref(cfg), LEN, LEN).decode() + "<16,10>/max3+vop2"
 
     from importlib import import_module
     sharding = import_module("parasail_rs_amd.sharding")
@@ -221,7 +221,7 @@ def main():
 
     if rank == 0:
         achieved = ALGO_BYTES_PER_PAIR * n / (kern_ms * 1e-3) / 1e9
-        valu_peak_gcups = VOP3P_INSTR_PER_S * 128.0 / PK_OPS_PER_CELL_PAIR / 1e9
+        valu_peak_gcups = SIMD_CYCLES_PER_S / CYCLES_PER_128_CELLS * 128.0 / 1e9
         kern_gcups = cells_per_rank_step / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "GCUPS (cell updates/s) local-affine SW, 1M 150x150 pairs, 1/2/4/8 GPUs",
@@ -239,8 +239,8 @@ def main():
                          "note": "312 algorithmic B/pair; the path is VALU-bound, see roofline_valu"},
             "roofline_valu": {"bound": "valu", "achieved": round(kern_gcups, 2), "peak": round(valu_peak_gcups, 1),
                               "unit": "GCUPS", "frac": round(kern_gcups / valu_peak_gcups, 4),
-                              "model": "11 VOP3P instr per 128 cells; measured issue rate 1 VOP3P wave64 instr / 4 cycles / SIMD, "
-                                       "1024 SIMDs, 2.4 GHz"},
+                              "model": "per 128 cells: 5.5 VOP3/VOP3P x 4 cycles + 4 VOP2 x 2 cycles = 30 SIMD cycles; "
+                                       "1024 SIMDs x 2.4 GHz (measured issue rates, profiles/r01)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_out = cpu_baseline(qbuf, qoff, rbuf, roff)

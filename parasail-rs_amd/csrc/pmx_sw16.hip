@@ -75,7 +75,7 @@ __device__ __forceinline__ v2s pk_max3f(v2s a, v2s b, v2s c)   // integer max3 o
 }
 #define FLOOR2 0x80008000   // both halves = -32768 = "zero" of the offset domain
 
-template <int G, int R, bool M3>
+template <int G, int R, int VAR>
 __global__ __launch_bounds__(64)
 void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                      const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
@@ -86,6 +86,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                      pmx_record_t *__restrict__ out)
 {
     static_assert(R % 2 == 0, "rows are stored two per dword");
+    constexpr bool M3 = VAR >= 1;      // biased unsigned lanes, v_pk_maximum3_f16 as integer max3
+    constexpr bool V2 = VAR == 2;      // + full-rate 32-bit VOP2 add/sub on packed lanes (no cross-half carry)
     constexpr int QP = G * R;            // padded query rows per pair
     constexpr int QP2 = QP / 2;          // dwords per profile row
     constexpr int SLOTS = 64 / G;
@@ -172,15 +174,15 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 const int q1 = v1[u] ? map[r1[u]] : -1;
                 int *pp = reinterpret_cast<int *>(prof) + p * (PROF_STRIDE / 4) + rp;
                 for (int sym = 0; sym < msize; ++sym) {
-                    const int s0 = (q0 < 0) ? 0 : mat[q0 * msize + sym];
-                    const int s1 = (q1 < 0) ? 0 : mat[q1 * msize + sym];
+                    const int s0 = ((q0 < 0) ? 0 : mat[q0 * msize + sym]) + (V2 ? open : 0);
+                    const int s1 = ((q1 < 0) ? 0 : mat[q1 * msize + sym]) + (V2 ? open : 0);
                     pp[sym * QP2] = (s0 & 0xFFFF) | (s1 << 16);
                 }
             }
         }
     }
     for (int idx = lane; idx < QP2; idx += 64)
-        reinterpret_cast<int *>(prof)[NP * (PROF_STRIDE / 4) + idx] = FLOOR2;
+        reinterpret_cast<int *>(prof)[NP * (PROF_STRIDE / 4) + idx] = V2 ? 0 : FLOOR2;
     __syncthreads();
 
     // ---- systolic sweep ---------------------------------------------------------------
@@ -202,13 +204,16 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     // Two copies of the H strip: a step reads one and writes the other, so the loop-carried
     // values never have to be moved between registers.
     v2s HA[R], HB[R], E[R], Hsave[R];
+    // V2: the strips hold H - open (the diagonal source), E starts at its exact value -open
+    const v2s vInitH = V2 ? PK(ZERO2 - I32(vOpen)) : vZero;
 #pragma unroll
-    for (int k = 0; k < R; ++k) { HA[k] = vZero; HB[k] = vZero; E[k] = M3 ? PK(0) : vZero; Hsave[k] = vZero; }
+    for (int k = 0; k < R; ++k) { HA[k] = vInitH; HB[k] = vInitH; E[k] = V2 ? vInitH : (M3 ? PK(0) : vZero); Hsave[k] = vZero; }
     v2s best = vZero;
     int bestcol = 0;
     int jj = ((-g) & 0xFFFF) * 0x00010001;    // packed column index of this lane
-    int Hout = ZERO2, Fout = ZERO2;           // last-row H and outgoing F of the previous step
-    v2s diag0 = vZero;                        // H(i0-1, j-1)
+    const int HNEUTRAL = V2 ? ZERO2 - I32(vOpen) : ZERO2;
+    int Hout = HNEUTRAL, Fout = ZERO2;        // last-row H (V2: H - open) and outgoing F of the previous step
+    v2s diag0 = PK(HNEUTRAL);                 // H(i0-1, j-1)   (V2: minus open)
 
     auto load_scores = [&](int symA, int symB, int (&wa)[R / 2], int (&wb)[R / 2]) {
         const int *sa = reinterpret_cast<const int *>(profA + symA * SYMSTRIDE);
@@ -217,15 +222,28 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         for (int k = 0; k < R / 2; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
     };
     auto step = [&](const v2s (&Hold)[R], v2s (&Hnew)[R], const int (&wa)[R / 2], const int (&wb)[R / 2]) {
-        const int Hin = group_shift_up<G>(Hout, ZERO2, g);    // H(i0-1, j)
+        const int Hin = group_shift_up<G>(Hout, HNEUTRAL, g); // H(i0-1, j)
         v2s F = PK(group_shift_up<G>(Fout, ZERO2, g));        // F(i0, j)
         v2s colmax = vZero;
+        v2s Hcur[R];                                           // V2 only: this column's H (the strips hold H - open)
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const v2s s = PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
             const v2s d = (k == 0) ? diag0 : Hold[k - 1];
             v2s H;
-            if (M3) {
+            if (V2) {
+                // Same domain as the max3 variant, but the strips carry H - open and the profile
+                // carries score + open (>= 0), so add and subtract never carry or borrow across
+                // the 16-bit halves and run as full-rate 32-bit VOP2 (v_add_u32 / v_sub_u32).
+                const v2s Tt = PK(I32(d) + I32(s));
+                H = pk_max3f(Tt, E[k], F);
+                const v2s Ho = PK(I32(H) - I32(vOpen));
+                E[k] = pk_max3f(PK(I32(E[k]) - I32(vExt)), Ho, Ho);
+                F = pk_max3f(PK(I32(F) - I32(vExt)), Ho, vZero);
+                Hnew[k] = Ho;
+                Hcur[k] = H;
+                if (k & 1) colmax = pk_max3f(colmax, Hcur[k - 1], H);
+            } else if (M3) {
                 // Biased unsigned lanes: every live value is 0 or in [1024, 31743], where the bit
                 // patterns of non-negative f16 order like integers, so v_pk_maximum3_f16 is an exact
                 // integer max3 (profiles/microbench/max3_f16_int.hip).  A pad score of -32768 sets the
@@ -264,7 +282,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             int hs;
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hs) : "v"(m), "v"(I32(Hnew[k])), "v"(I32(Hsave[k])));
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hs) : "v"(m), "v"(I32(V2 ? Hcur[k] : Hnew[k])), "v"(I32(Hsave[k])));
             Hsave[k] = PK(hs);
         }
         best = nb;
@@ -279,10 +297,14 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     for (int t = 0; t < T; t += 2) {
         load_scores(nsA, nsB, w1a, w1b);
         nsA = rsA[t + 2]; nsB = rsB[t + 2];
+        __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads ahead of the step they overlap with
         step(HA, HB, w0a, w0b);
+        __builtin_amdgcn_sched_barrier(0);
         load_scores(nsA, nsB, w0a, w0b);
         nsA = rsA[t + 3]; nsB = rsB[t + 3];
+        __builtin_amdgcn_sched_barrier(0);
         step(HB, HA, w1a, w1b);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- per lane: first row of the saved strip that holds the best ---------------------
@@ -327,7 +349,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 
 // ------------------------------------------------------------------------ host side ----
 
-template <int G, int R, bool M3>
+template <int G, int R, int VAR>
 static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                       pmx_record_t *d_out, hipStream_t stream)
 {
@@ -339,14 +361,14 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
     if (lds > 160 * 1024) return 1;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_sw16_kernel<G, R, M3>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_sw16_kernel<G, R, VAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL((pmx_sw16_kernel<G, R, M3>), dim3((unsigned)blocks), dim3(64), lds, stream,
+    hipLaunchKernelGGL((pmx_sw16_kernel<G, R, VAR>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                        m.msize, open, ext, RP, b.q_shared, M3_LIMIT(m.max), d_out);
     hipError_t e = hipGetLastError();
@@ -362,12 +384,18 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
     if (b.max_rlen > 60000) return 1;                 // 16-bit column index
     const int q = b.max_qlen;
     // max3 variant: gap penalties and the most negative score must keep every live value >= 1024
-    const bool m3 = !getenv("PMX_SW16_NO_M3") && open <= 1024 && ext <= 1024 && m.min >= -1024 && m.max <= 2048;
+    const char *force = getenv("PMX_SW16_VARIANT");
+    int var = 0;
+    if (open <= 1024 && ext <= 1024 && m.min >= -1024 && m.max <= 2048) var = 1;
+    // 32-bit add/sub variant: score + open must be non-negative, and E - extend must not borrow
+    if (var == 1 && m.min + open >= 0 && open + ext <= 1024) var = 2;
+    if (force && atoi(force) < var) var = atoi(force);
 #define TRY(GG, RR, NAME)                                                       \
     if (q <= (GG) * (RR)) {                                                     \
-        int rc = m3 ? launch_one<GG, RR, true>(b, m, open, ext, d_out, stream)  \
-                    : launch_one<GG, RR, false>(b, m, open, ext, d_out, stream);\
-        if (rc <= 0) { if (kernel_name) *kernel_name = m3 ? NAME "/max3" : NAME; return rc; }       \
+        int rc = var == 2 ? launch_one<GG, RR, 2>(b, m, open, ext, d_out, stream)  \
+               : var == 1 ? launch_one<GG, RR, 1>(b, m, open, ext, d_out, stream)  \
+                          : launch_one<GG, RR, 0>(b, m, open, ext, d_out, stream); \
+        if (rc <= 0) { if (kernel_name) *kernel_name = var == 2 ? NAME "/max3+vop2" : var == 1 ? NAME "/max3" : NAME; return rc; } \
     }
     TRY(16, 10, "pmx_sw16_kernel<16,10>")
     TRY(16, 16, "pmx_sw16_kernel<16,16>")

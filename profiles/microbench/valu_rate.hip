@@ -54,6 +54,39 @@ DEFINE_KERNEL(add3_u32,     "v_add3_u32 %0, %0, %1, %2")
 DEFINE_KERNEL(pk_mad_i16,   "v_pk_mad_i16 %0, %0, %1, %2")
 DEFINE_KERNEL(sad_u16,      "v_sad_u16 %0, %0, %1, %2")
 
+
+#define DEFINE_MIX(NAME, ASM_A, ASM_B)                                                      \
+__global__ __launch_bounds__(64) void k_##NAME(int *out, unsigned long long *cyc, int seed) \
+{                                                                                           \
+    int a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
+    int b = seed * 31 + 7, c = seed * 17 + 3;                                               \
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();                                   \
+    for (int i = 0; i < ITER; ++i) {                                                        \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                     \
+            asm volatile(ASM_A : "+v"(a0) : "v"(b), "v"(c));                                \
+            asm volatile(ASM_B : "+v"(a1) : "v"(b), "v"(c));                                \
+            asm volatile(ASM_A : "+v"(a2) : "v"(b), "v"(c));                                \
+            asm volatile(ASM_B : "+v"(a3) : "v"(b), "v"(c));                                \
+            asm volatile(ASM_A : "+v"(a4) : "v"(b), "v"(c));                                \
+            asm volatile(ASM_B : "+v"(a5) : "v"(b), "v"(c));                                \
+            asm volatile(ASM_A : "+v"(a6) : "v"(b), "v"(c));                                \
+            asm volatile(ASM_B : "+v"(a7) : "v"(b), "v"(c));                                \
+        }                                                                                   \
+    }                                                                                       \
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();                                   \
+    out[blockIdx.x * 64 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;            \
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;                                        \
+}
+DEFINE_MIX(mix_max3_sub, "v_pk_maximum3_f16 %0, %0, %1, %2", "v_sub_u32 %0, %0, %1")
+DEFINE_MIX(mix_pkmax_add, "v_pk_max_i16 %0, %0, %1", "v_add_u32 %0, %0, %1")
+DEFINE_MIX(mix_sub_add, "v_sub_u32 %0, %0, %1", "v_add_u32 %0, %0, %1")
+DEFINE_MIX(mix_sub_xor, "v_sub_u32 %0, %0, %1", "v_xor_b32 %0, %0, %1")
+DEFINE_KERNEL(sub_u32,      "v_sub_u32 %0, %0, %1")
+DEFINE_KERNEL(subrev_u32,   "v_subrev_u32 %0, %1, %0")
+DEFINE_KERNEL(xor_b32,      "v_xor_b32 %0, %0, %1")
+DEFINE_KERNEL(max_u16,      "v_max_u16 %0, %0, %1")
+DEFINE_KERNEL(lshl,         "v_lshlrev_b32 %0, 1, %0")
+
 typedef void (*kfn)(int *, unsigned long long *, int);
 struct Entry { const char *name; kfn f; };
 
@@ -65,7 +98,7 @@ int main()
         {"v_pk_add_u16", k_pk_add_u16}, {"v_perm_b32", k_perm_b32}, {"v_bfi_b32", k_bfi_b32},
         {"v_pk_max_f16", k_pk_max_f16}, {"v_pk_add_f16", k_pk_add_f16}, {"v_pk_maximum3_f16", k_pk_max3_f16},
         {"v_mov_b32_dpp row_shr:1", k_mov_dpp}, {"v_max_i16", k_max_i16}, {"v_add_f32", k_add_f32},
-        {"v_add3_u32", k_add3_u32}, {"v_pk_mad_i16", k_pk_mad_i16}, {"v_sad_u16", k_sad_u16},
+        {"v_add3_u32", k_add3_u32}, {"v_sub_u32", k_sub_u32}, {"v_subrev_u32", k_subrev_u32}, {"v_xor_b32", k_xor_b32}, {"v_max_u16", k_max_u16}, {"v_lshlrev_b32", k_lshl}, {"mix max3_f16 + sub_u32", k_mix_max3_sub}, {"mix pk_max_i16 + add_u32", k_mix_pkmax_add}, {"mix sub_u32 + add_u32", k_mix_sub_add}, {"mix sub_u32 + xor", k_mix_sub_xor}, {"v_pk_mad_i16", k_pk_mad_i16}, {"v_sad_u16", k_sad_u16},
     };
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
