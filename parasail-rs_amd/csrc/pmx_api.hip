@@ -883,11 +883,12 @@ static int scratch_reserve(size_t bytes, void **out)
     return 0;
 }
 
-extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
-                                      const uint8_t *d_qbuf, const int64_t *d_qoff,
-                                      const uint8_t *d_rbuf, const int64_t *d_roff,
-                                      int32_t max_qlen, int32_t max_rlen,
-                                      pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream)
+// Device-resident batch.  q_shared > 0: every pair uses the one query d_qbuf[0..q_shared) (profile arm).
+static int run_batch_device(const pmx_config_t *cfg, int64_t n,
+                            const uint8_t *d_qbuf, const int64_t *d_qoff, int q_shared,
+                            const uint8_t *d_rbuf, const int64_t *d_roff,
+                            int32_t max_qlen, int32_t max_rlen,
+                            pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream)
 {
     if (check_cfg(cfg)) return -1;
     if (n <= 0) return 0;
@@ -897,7 +898,7 @@ extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
     DevMat dm;
     if (get_devmat(cfg->matrix, &dm)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, max_qlen, max_rlen, 0};
+    PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, max_qlen, max_rlen, q_shared};
     if (fast_sw_eligible(cfg)) {
         const int rc = pmx_launch_sw16(b, dm.d, cfg->open, cfg->extend, d_out, st, nullptr);
         if (rc < 0) { set_err("sw16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
@@ -922,7 +923,8 @@ extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
             const size_t stride2 = (size_t)8 * max_rlen;
             bnd.alloc((size_t)count * stride2);
             PmxGeneralArgs a; memset(&a, 0, sizeof a);
-            a.qbuf = d_qbuf; a.qoff = d_qoff; a.rbuf = d_rbuf; a.roff = d_roff; a.n = count; a.index = list.p;
+            a.qbuf = d_qbuf; a.qoff = q_shared ? nullptr : d_qoff; a.shared_qlen = q_shared;
+            a.rbuf = d_rbuf; a.roff = d_roff; a.n = count; a.index = list.p;
             a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
             a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
             a.bits = cfg->width == 16 ? 16 : 32; a.bound = bnd.p; a.bound_stride = (long long)stride2; a.rec = d_out;
@@ -938,7 +940,8 @@ extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
     const size_t stride = (size_t)8 * max_rlen;
     if (scratch_reserve((size_t)n * stride * sizeof(int32_t), &bound)) return -1;
     PmxGeneralArgs a; memset(&a, 0, sizeof a);
-    a.qbuf = d_qbuf; a.qoff = d_qoff; a.rbuf = d_rbuf; a.roff = d_roff; a.n = n;
+    a.qbuf = d_qbuf; a.qoff = q_shared ? nullptr : d_qoff; a.shared_qlen = q_shared;
+    a.rbuf = d_rbuf; a.roff = d_roff; a.n = n;
     a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize; a.pssm = 0;
     a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
     a.bits = cfg->width;
@@ -947,6 +950,15 @@ extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
     const int rc = pmx_launch_general(a, (cfg->want & PMX_WANT_STATS) != 0, st);
     if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
     return 0;
+}
+
+extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
+                                      const uint8_t *d_qbuf, const int64_t *d_qoff,
+                                      const uint8_t *d_rbuf, const int64_t *d_roff,
+                                      int32_t max_qlen, int32_t max_rlen,
+                                      pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream)
+{
+    return run_batch_device(cfg, n, d_qbuf, d_qoff, 0, d_rbuf, d_roff, max_qlen, max_rlen, d_out, d_stats_out, stream);
 }
 
 static void host_maxlens(int64_t n, const int64_t *off, int32_t *mx, bool *bad)
@@ -1010,18 +1022,9 @@ extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_p
     HIP_OR_RET(hipMemcpy(dq.p, profile->s1, profile->s1Len, hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
-    void *bound = nullptr;
-    const size_t stride = (size_t)8 * mr;
-    if (scratch_reserve((size_t)n * stride * sizeof(int32_t), &bound)) return -1;
-    PmxGeneralArgs a; memset(&a, 0, sizeof a);
-    a.qbuf = dq.p; a.qoff = nullptr; a.shared_qlen = profile->s1Len; a.rbuf = dr.p; a.roff = dro.p; a.n = n;
-    a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
-    a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
-    a.bits = cfg->width;
-    a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
-    a.rec = drec.p; a.stats = stats ? dst.p : nullptr;
-    const int rc = pmx_launch_general(a, stats, nullptr);
-    if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    const int rc = run_batch_device(cfg, n, dq.p, nullptr, profile->s1Len, dr.p, dro.p, profile->s1Len, mr,
+                                    drec.p, stats ? dst.p : nullptr, nullptr);
+    if (rc) return rc;
     HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
     if (stats) HIP_OR_RET(hipMemcpy(stats_out, dst.p, sizeof(pmx_stats_t) * n, hipMemcpyDeviceToHost));
     return 0;

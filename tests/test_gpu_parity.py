@@ -356,6 +356,29 @@ def test_profile_batch_nw_stats_blosum62(pkg, orc):
     assert one.get_score() == rec["score"][0] and one.get_matches() == st["matches"][0]
 
 
+def test_profile_batch_sw_sat_mixed_lengths(pkg, orc):
+    """BASELINE config 5 shape, reduced: one 1 kbp query (reused profile) against references of mixed
+    length, `sw_striped_profile_sat`; a second matrix forces the int16 -> 32-bit promotion."""
+    rng = np.random.default_rng(2550)
+    q = random_seqs(rng, 1, 1000, 1000)[0]
+    lens = np.exp(rng.uniform(np.log(500), np.log(5000), size=60)).astype(int)
+    rs = [DNA[rng.integers(0, 4, size=int(l))].tobytes() for l in lens]
+    for k in range(0, 60, 7):                       # plant noisy copies of the query
+        pos = int(rng.integers(0, max(1, len(rs[k]) - 10)))
+        rs[k] = rs[k][:pos] + mutate(rng, q, 0.05, 0.01) + rs[k][pos:]
+    for match, mism in ((2, -3), (40, -40)):
+        pm, om = pkg.Matrix.create(b"ACGT", match, mism), orc.Matrix.create("ACGT", match, mism)
+        al = pkg.Aligner.new().local().profile(pkg.Profile.new(q, False, pm)).matrix(pm).gap_open(5).gap_extend(2).build()
+        assert al.fn_name == "sw_striped_profile_sat"
+        got = al.align_batch([], rs)
+        qb, qo = orc.pack([q] * len(rs)); rb, ro = orc.pack(rs)
+        want = orc.align_batch(orc.SW, qb, qo, rb, ro, 5, 2, om)
+        assert (got["score"] == want[:, 0]).all() and (got["end_query"] == want[:, 1]).all() \
+            and (got["end_ref"] == want[:, 2]).all() and (got["flags"] == 0).all()
+        if match == 40:
+            assert got["score"].max() > 32767
+
+
 def test_batch_cigar_semi_global(pkg, orc):
     """BASELINE config 4 shape, reduced: sg + traceback + CIGAR, walk done on the device"""
     rng = np.random.default_rng(2600)
