@@ -449,7 +449,7 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
     HIP_OR_DIE(hipMemcpy(doff.p, offs, sizeof offs, hipMemcpyHostToDevice));
 
     PmxGeneralArgs a; memset(&a, 0, sizeof a);
-    a.qbuf = dq.p; a.qoff = doff.p; a.rbuf = dr.p; a.roff = doff.p + 2; a.n = 1;
+    a.qbuf = dq.p; a.qoff = doff.p; a.rbuf = dr.p; a.roff = doff.p + 2; a.n = 1; a.max_rlen = s2Len;
     a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize;
     a.mat_rows = matrix->length; a.pssm = pssm ? 1 : 0;
     a.mode = sp.mode; a.sg_flags = sp.sg_flags; a.open = open; a.ext = gap; a.band = sp.band;
@@ -924,7 +924,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
             bnd.alloc((size_t)count * stride2);
             PmxGeneralArgs a; memset(&a, 0, sizeof a);
             a.qbuf = d_qbuf; a.qoff = q_shared ? nullptr : d_qoff; a.shared_qlen = q_shared;
-            a.rbuf = d_rbuf; a.roff = d_roff; a.n = count; a.index = list.p;
+            a.rbuf = d_rbuf; a.roff = d_roff; a.n = count; a.index = list.p; a.max_rlen = max_rlen;
             a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
             a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
             a.bits = cfg->width == 16 ? 16 : 32; a.bound = bnd.p; a.bound_stride = (long long)stride2; a.rec = d_out;
@@ -941,7 +941,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
     if (scratch_reserve((size_t)n * stride * sizeof(int32_t), &bound)) return -1;
     PmxGeneralArgs a; memset(&a, 0, sizeof a);
     a.qbuf = d_qbuf; a.qoff = q_shared ? nullptr : d_qoff; a.shared_qlen = q_shared;
-    a.rbuf = d_rbuf; a.roff = d_roff; a.n = n;
+    a.rbuf = d_rbuf; a.roff = d_roff; a.n = n; a.max_rlen = max_rlen;
     a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize; a.pssm = 0;
     a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
     a.bits = cfg->width;
@@ -1069,7 +1069,7 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
     const size_t stride = (size_t)8 * mr;
     if (scratch_reserve((size_t)n * stride * sizeof(int32_t), &bound)) return -1;
     PmxGeneralArgs a; memset(&a, 0, sizeof a);
-    a.qbuf = dq.p; a.qoff = dqo.p; a.rbuf = dr.p; a.roff = dro.p; a.n = n;
+    a.qbuf = dq.p; a.qoff = dqo.p; a.rbuf = dr.p; a.roff = dro.p; a.n = n; a.max_rlen = mr;
     a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
     a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
     a.bits = cfg->width;

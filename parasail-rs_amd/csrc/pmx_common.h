@@ -35,6 +35,7 @@ struct PmxGeneralArgs {
     const uint8_t *qbuf; const int64_t *qoff;     // qoff == nullptr: one shared query of shared_qlen bytes at qbuf
     const uint8_t *rbuf; const int64_t *roff;
     long long n;
+    int max_rlen;             // longest reference in the launch (sizes the LDS symbol buffer)
     const int64_t *index;     // optional: block b works on pair index[b] (promotion re-runs); n = number of blocks
     int shared_qlen;
     const int16_t *scores; const uint8_t *mapper; int msize;

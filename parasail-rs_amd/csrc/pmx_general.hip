@@ -32,6 +32,9 @@
 
 struct Cand { int H, i, j, M, S, L; };
 
+// value of lane-1 (DPP wave_shr:1; lane 0 keeps its own value, which the caller overrides)
+__device__ __forceinline__ int lane_up(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xF, 0xF, false); }
+
 // true if a should replace b under "larger H, then smaller j, then smaller i"
 __device__ __forceinline__ bool better_sw(const Cand &a, const Cand &b)
 {
@@ -68,17 +71,22 @@ void pmx_general_kernel(const PmxGeneralArgs a)
     const int msize = a.msize;
 
     for (int i = lane; i < a.mat_rows * msize; i += 64) mat[i] = a.scores[i];
-    __syncthreads();
 
     long long qb, rb; int ql, rl;
     if (a.qoff) { qb = a.qoff[pair]; ql = (int)(a.qoff[pair + 1] - qb); }
     else { qb = 0; ql = a.shared_qlen; }
     rb = a.roff[pair]; rl = (int)(a.roff[pair + 1] - rb);
     const uint8_t *q = a.qbuf + qb, *r = a.rbuf + rb;
+    // mapped reference symbols live in LDS for the whole pair (the sweep reads one per lane and step;
+    // fetching them from HBM inside the loop made every step wait for two dependent global loads)
+    unsigned char *rs = lds + (((size_t)a.mat_rows * msize * 2 + 15) & ~(size_t)15);
+    for (int j = lane; j < rl; j += 64) rs[j] = a.mapper[r[j]];
+    for (int j = rl + lane; j < rl + 4; j += 64) rs[j] = 0;
+    __syncthreads();
     const long long tab0 = a.tab_off ? a.tab_off[pair] : 0;
     const long long row0 = (a.n > 1 || a.index) ? rb : 0;     // row outputs packed like the references
     const long long col0 = (a.n > 1 && a.qoff) ? qb : (a.qoff ? 0 : pair * (long long)ql);
-    volatile int32_t *bound = a.bound + (long long)blockIdx.x * a.bound_stride;
+    int32_t *bound = a.bound + (long long)blockIdx.x * a.bound_stride;
 
     const int mode = a.mode, open = a.open, ext = a.ext, band_w = a.band;
     const bool s1_beg = mode == PMX_MODE_SG && (a.sg_flags & PMX_SG_QB);
@@ -110,15 +118,29 @@ void pmx_general_kernel(const PmxGeneralArgs a)
         // what this lane hands to the lane below: H(i,j), F(i,j) and stats
         int oH = NEG_INF, oF = NEG_INF, oHM = 0, oHS = 0, oHL = 0, oFM = 0, oFS = 0, oFL = 0;
 
+        // lane 0 reads the previous band's last row one column ahead of its use
+        int pb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (lane == 0 && bandi > 0) {
+            pb[0] = bound[0]; pb[1] = bound[1];
+            if (STATS) { for (int x = 2; x < 8; ++x) pb[x] = bound[x]; }
+        }
+        // two-stage LDS pipeline: symbol of column j+2, score of column j+1
+        int sym_n = rs[max(0, min(rl, 1 - lane))];
+        int s_n = mrow[rs[max(0, min(rl, 0 - lane))]];
+
         const int steps = rl + 63;
         for (int t = 0; t < steps; ++t) {
             const int j = t - lane;
+            const int s = s_n;                       // score for column j
+            const int rsym_cur = rs[max(0, min(rl, j))];
+            s_n = mrow[sym_n];
+            sym_n = rs[max(0, min(rl, j + 2))];
             // --- values of the row above for column j (produced one step ago by lane-1) ---
-            int upH = __shfl_up(oH, 1, 64), upF = __shfl_up(oF, 1, 64);
+            int upH = lane_up(oH), upF = lane_up(oF);
             int upHM = 0, upHS = 0, upHL = 0, upFM = 0, upFS = 0, upFL = 0;
             if (STATS) {
-                upHM = __shfl_up(oHM, 1, 64); upHS = __shfl_up(oHS, 1, 64); upHL = __shfl_up(oHL, 1, 64);
-                upFM = __shfl_up(oFM, 1, 64); upFS = __shfl_up(oFS, 1, 64); upFL = __shfl_up(oFL, 1, 64);
+                upHM = lane_up(oHM); upHS = lane_up(oHS); upHL = lane_up(oHL);
+                upFM = lane_up(oFM); upFS = lane_up(oFS); upFL = lane_up(oFL);
             }
             const bool active = row_ok && j >= 0 && j < rl;
             if (lane == 0 && j < rl) {
@@ -129,16 +151,16 @@ void pmx_general_kernel(const PmxGeneralArgs a)
                     upFM = upFS = upFL = 0;
                     hmin = min(hmin, upH);
                 } else {
-                    upH = bound[8LL * j + 0]; upF = bound[8LL * j + 1];
-                    if (STATS) {
-                        upHM = bound[8LL * j + 2]; upHS = bound[8LL * j + 3]; upHL = bound[8LL * j + 4];
-                        upFM = bound[8LL * j + 5]; upFS = bound[8LL * j + 6]; upFL = bound[8LL * j + 7];
+                    upH = pb[0]; upF = pb[1];
+                    if (STATS) { upHM = pb[2]; upHS = pb[3]; upHL = pb[4]; upFM = pb[5]; upFS = pb[6]; upFL = pb[7]; }
+                    if (j + 1 < rl) {
+                        pb[0] = bound[8LL * (j + 1) + 0]; pb[1] = bound[8LL * (j + 1) + 1];
+                        if (STATS) { for (int x = 2; x < 8; ++x) pb[x] = bound[8LL * (j + 1) + x]; }
                     }
                 }
             }
             if (active) {
-                const int rsym = a.mapper[r[j]];
-                const int s = mrow[rsym];
+                const int rsym = rsym_cur;
                 int T = 0;
                 int F, FM, FS, FL;
                 {
@@ -217,6 +239,11 @@ void pmx_general_kernel(const PmxGeneralArgs a)
                 }
             }
         }
+        // the next band's lane 0 reads what this band's lane 63 stored: drain the stores, drop stale L1 lines
+        if (bandi + 1 < nbands) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
     }
 
     // ---- wave reduction ---------------------------------------------------------------
@@ -249,8 +276,18 @@ void pmx_general_kernel(const PmxGeneralArgs a)
 int pmx_launch_general(const PmxGeneralArgs &a, bool want_stats, hipStream_t stream)
 {
     if (a.n <= 0) return 0;
-    const size_t lds = (size_t)a.mat_rows * a.msize * 2;
-    if (lds > 64 * 1024) return 1;
+    const size_t lds = (((size_t)a.mat_rows * a.msize * 2 + 15) & ~(size_t)15) + (size_t)a.max_rlen + 8;
+    if (lds > 160 * 1024) return 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        const void *fns[4] = {(const void *)&pmx_general_kernel<true, true>, (const void *)&pmx_general_kernel<true, false>,
+                              (const void *)&pmx_general_kernel<false, true>, (const void *)&pmx_general_kernel<false, false>};
+        for (const void *f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return -(int)e;
+        }
+        attr_done = true;
+    }
     const bool out = a.score_table || a.trace_table || a.score_row || a.score_col ||
                      a.matches_table || a.similar_table || a.length_table;
     dim3 grid((unsigned)a.n), block(64);

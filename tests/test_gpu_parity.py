@@ -197,6 +197,24 @@ def test_sw16_file_matrix_asymmetric(pkg, orc):
     _fast_case(pkg, orc, qs, rs, 5, 2, pm, om)
 
 
+def test_sw16_saturating_int16_variant(pkg, orc):
+    """scores too large for the max3 lanes (matrix max > 2048) take the saturating-int16 variant"""
+    rng = np.random.default_rng(1450)
+    pm, om = pkg.Matrix.create(b"ACGT", 3000, -3000), orc.Matrix.create("ACGT", 3000, -3000)
+    qs = random_seqs(rng, 200, 1, 40)
+    rs = [mutate(rng, q, 0.2, 0.1) for q in qs]
+    got = pkg.Aligner.new().local().matrix(pm).gap_open(4000).gap_extend(100).solution_width(16).build().align_batch(qs, rs)
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    want = orc.align_batch(orc.SW, qb, qo, rb, ro, 4000, 100, om)
+    ok = want[:, 0] <= 32767
+    assert ok.sum() > 50 and (~ok).sum() > 5
+    assert (got["score"][ok] == want[ok, 0]).all() and (got["end_query"][ok] == want[ok, 1]).all() \
+        and (got["end_ref"][ok] == want[ok, 2]).all() and (got["flags"][ok] == 0).all()
+    assert (got["flags"][~ok] & pkg.FLAG_SATURATED).all()
+    sat = pkg.Aligner.new().local().matrix(pm).gap_open(4000).gap_extend(100).build().align_batch(qs, rs)
+    assert (sat["score"] == want[:, 0]).all() and (sat["flags"] == 0).all()
+
+
 def test_sw16_saturation_flag_and_promotion(pkg, orc):
     pm, om = pkg.Matrix.create(b"ACGT", 40, -40), orc.Matrix.create("ACGT", 40, -40)
     q = b"ACGT" * 250
