@@ -869,9 +869,11 @@ extern "C" const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen,
 
 // grow-only per-(thread,device) scratch for the general kernel's band boundary rows
 struct Scratch { void *p = nullptr; size_t cap = 0; int dev = -1; };
-static thread_local Scratch g_scratch;
-static int scratch_reserve(size_t bytes, void **out)
+enum { SCR_BOUND = 0, SCR_TRACE = 1, SCR_OPS = 2, SCR_SLOTS = 3 };
+static thread_local Scratch g_scratch_pool[SCR_SLOTS];
+static int scratch_reserve(size_t bytes, void **out, int slot = SCR_BOUND)
 {
+    Scratch &g_scratch = g_scratch_pool[slot];
     int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
     if (g_scratch.dev != dev || g_scratch.cap < bytes) {
         if (g_scratch.p && g_scratch.dev == dev) (void)hipFree(g_scratch.p);
@@ -1056,9 +1058,11 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
     }
     const size_t qbytes = (size_t)qoff[n], rbytes = (size_t)roff[n];
     DevBuf<uint8_t> dq, dr; DevBuf<int64_t> dqo, dro, dto, doo; DevBuf<pmx_record_t> drec;
-    DevBuf<int8_t> dtrace; DevBuf<uint32_t> dops; DevBuf<int32_t> dnops, dbeg;
+    struct { int8_t *p; } dtrace; struct { uint32_t *p; } dops; DevBuf<int32_t> dnops, dbeg;   // trace/ops: pooled scratch
     dq.alloc(qbytes); dr.alloc(rbytes); dqo.alloc(n + 1); dro.alloc(n + 1); dto.alloc(n + 1); doo.alloc(n + 1);
-    drec.alloc(n); dtrace.alloc((size_t)tab_off[n]); dops.alloc((size_t)ops_off[n]); dnops.alloc(n); dbeg.alloc(2 * n);
+    drec.alloc(n); dnops.alloc(n); dbeg.alloc(2 * n);
+    if (scratch_reserve((size_t)tab_off[n], (void **)&dtrace.p, SCR_TRACE)) return -1;
+    if (scratch_reserve((size_t)ops_off[n] * sizeof(uint32_t), (void **)&dops.p, SCR_OPS)) return -1;
     HIP_OR_RET(hipMemcpy(dq.p, qbuf, qbytes, hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dqo.p, qoff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
@@ -1083,16 +1087,30 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
     w.ops = dops.p; w.ops_off = doo.p; w.nops = dnops.p; w.beg = dbeg.p;
     rc = pmx_launch_walk(w, nullptr);
     if (rc) { set_err("walk kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
-    std::vector<uint32_t> ops((size_t)ops_off[n]); std::vector<int32_t> nops(n);
+    // only the runs actually produced come back: nops first, then a dense copy of the ops
+    std::vector<int32_t> nops(n);
     HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
-    HIP_OR_RET(hipMemcpy(ops.data(), dops.p, sizeof(uint32_t) * ops.size(), hipMemcpyDeviceToHost));
     HIP_OR_RET(hipMemcpy(nops.data(), dnops.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    std::vector<int64_t> dense_off(n + 1);
+    dense_off[0] = 0;
+    for (int64_t k = 0; k < n; ++k) dense_off[k + 1] = dense_off[k] + nops[k];
+    DevBuf<int64_t> ddo; DevBuf<uint32_t> ddense;
+    ddo.alloc(n + 1); ddense.alloc((size_t)dense_off[n]);
+    HIP_OR_RET(hipMemcpy(ddo.p, dense_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    rc = pmx_launch_compact_ops(dops.p, doo.p, dnops.p, ddo.p, ddense.p, n, nullptr);
+    if (rc) { set_err("compaction kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    std::vector<uint32_t> ops((size_t)dense_off[n] + 1);
+    HIP_OR_RET(hipMemcpy(ops.data(), ddense.p, sizeof(uint32_t) * (size_t)dense_off[n], hipMemcpyDeviceToHost));
     std::string text;
+    text.reserve((size_t)dense_off[n] * 4);
     cigar_off[0] = 0;
+    char num[16];
     for (int64_t k = 0; k < n; ++k) {
-        for (int t = 0; t < nops[k]; ++t) {
-            const uint32_t o = ops[(size_t)ops_off[k] + t];
-            text += std::to_string(o >> 4);
+        for (int64_t t = dense_off[k]; t < dense_off[k + 1]; ++t) {
+            const uint32_t o = ops[(size_t)t];
+            uint32_t v = o >> 4; int len = 0;
+            do { num[len++] = (char)('0' + v % 10); v /= 10; } while (v);
+            while (len) text.push_back(num[--len]);
             text.push_back(BAM_OPS[o & 0xF]);
         }
         cigar_off[k + 1] = (int64_t)text.size();

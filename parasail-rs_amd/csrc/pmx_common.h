@@ -52,6 +52,7 @@ struct PmxGeneralArgs {
     const int64_t *tab_off;
     int32_t *score_table, *matches_table, *similar_table, *length_table;
     int8_t *trace_table;
+    int trace_lds;            // set by the launcher: stage one band of trace bytes in LDS, flush coalesced
     // row/col outputs: row offset = roff[k], col offset = qoff[k] (or 0 for n == 1)
     int32_t *score_row, *matches_row, *similar_row, *length_row;
     int32_t *score_col, *matches_col, *similar_col, *length_col;
@@ -69,6 +70,8 @@ struct PmxWalkArgs {
     uint32_t *ops; const int64_t *ops_off; int32_t *nops; int32_t *beg; /* 2 per pair */
 };
 int pmx_launch_walk(const PmxWalkArgs &a, hipStream_t stream);
+int pmx_launch_compact_ops(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops,
+                           const int64_t *dense_off, uint32_t *dense, long long n, hipStream_t stream);
 
 // Collect the indices of records whose flags intersect `mask`: list[0..*count) (device), any order.
 int pmx_launch_collect_saturated(const pmx_record_t *rec, long long n, int64_t *list, int *count, int mask, hipStream_t stream);

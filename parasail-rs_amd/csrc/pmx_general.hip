@@ -83,6 +83,9 @@ void pmx_general_kernel(const PmxGeneralArgs a)
     for (int j = lane; j < rl; j += 64) rs[j] = a.mapper[r[j]];
     for (int j = rl + lane; j < rl + 4; j += 64) rs[j] = 0;
     __syncthreads();
+    // optional staging area for one band of trace bytes (64 rows x rl), flushed with wide stores
+    unsigned char *tstage = rs + (((size_t)a.max_rlen + 8 + 15) & ~(size_t)15);
+    const bool tlds = OUT && a.trace_table && a.trace_lds;
     const long long tab0 = a.tab_off ? a.tab_off[pair] : 0;
     const long long row0 = (a.n > 1 || a.index) ? rb : 0;     // row outputs packed like the references
     const long long col0 = (a.n > 1 && a.qoff) ? qb : (a.qoff ? 0 : pair * (long long)ql);
@@ -118,6 +121,11 @@ void pmx_general_kernel(const PmxGeneralArgs a)
         // what this lane hands to the lane below: H(i,j), F(i,j) and stats
         int oH = NEG_INF, oF = NEG_INF, oHM = 0, oHS = 0, oHL = 0, oFM = 0, oFS = 0, oFL = 0;
 
+        int8_t *tdst = nullptr; unsigned char *ts = nullptr;
+        if (tlds) {
+            tdst = a.trace_table + tab0 + (long long)bandi * 64 * rl;
+            ts = tstage + ((uintptr_t)tdst & 15);          // same alignment mod 16 as the destination
+        }
         // lane 0 reads the previous band's last row one column ahead of its use
         int pb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (lane == 0 && bandi > 0) {
@@ -201,7 +209,8 @@ void pmx_general_kernel(const PmxGeneralArgs a)
                         if (a.similar_table) a.similar_table[c] = HS;
                         if (a.length_table) a.length_table[c] = HL;
                     }
-                    if (a.trace_table) a.trace_table[c] = (int8_t)T;
+                    if (tlds) ts[lane * rl + j] = (unsigned char)T;
+                    else if (a.trace_table) a.trace_table[c] = (int8_t)T;
                     if (i == ql - 1) {
                         if (a.score_row) a.score_row[row0 + j] = H;
                         if (STATS) {
@@ -239,6 +248,18 @@ void pmx_general_kernel(const PmxGeneralArgs a)
                 }
             }
         }
+        if (tlds) {   // flush the staged band: rows of a band are contiguous in the row-major table
+            __syncthreads();
+            const int nbytes = min(64, ql - bandi * 64) * rl;
+            const int head = min(nbytes, (int)((16 - ((uintptr_t)tdst & 15)) & 15));
+            if (lane < head) tdst[lane] = (int8_t)ts[lane];
+            int k = head + lane * 16;
+            for (; k + 16 <= nbytes; k += 64 * 16)
+                *reinterpret_cast<int4 *>(tdst + k) = *reinterpret_cast<const int4 *>(ts + k);
+            const int tail0 = head + ((nbytes - head) / 16) * 16;
+            for (int b = tail0 + lane; b < nbytes; b += 64) tdst[b] = (int8_t)ts[b];
+            __syncthreads();
+        }
         // the next band's lane 0 reads what this band's lane 63 stored: drain the stores, drop stale L1 lines
         if (bandi + 1 < nbands) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -273,11 +294,14 @@ void pmx_general_kernel(const PmxGeneralArgs a)
     }
 }
 
-int pmx_launch_general(const PmxGeneralArgs &a, bool want_stats, hipStream_t stream)
+int pmx_launch_general(const PmxGeneralArgs &a_in, bool want_stats, hipStream_t stream)
 {
-    if (a.n <= 0) return 0;
-    const size_t lds = (((size_t)a.mat_rows * a.msize * 2 + 15) & ~(size_t)15) + (size_t)a.max_rlen + 8;
+    if (a_in.n <= 0) return 0;
+    PmxGeneralArgs a = a_in;
+    size_t lds = (((size_t)a.mat_rows * a.msize * 2 + 15) & ~(size_t)15) + (((size_t)a.max_rlen + 8 + 15) & ~(size_t)15);
     if (lds > 160 * 1024) return 1;
+    a.trace_lds = 0;
+    if (a.trace_table && lds + (size_t)64 * a.max_rlen + 32 <= 96 * 1024) { a.trace_lds = 1; lds += (size_t)64 * a.max_rlen + 32; }
     static bool attr_done = false;
     if (!attr_done) {
         const void *fns[4] = {(const void *)&pmx_general_kernel<true, true>, (const void *)&pmx_general_kernel<true, false>,
@@ -383,5 +407,27 @@ int pmx_launch_collect_saturated(const pmx_record_t *rec, long long n, int64_t *
     if (e != hipSuccess) return -(int)e;
     hipLaunchKernelGGL(pmx_collect_saturated_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, n, list, count, mask);
     e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+// Dense copy of the run-length ops: pair k's nops[k] runs move from ops[ops_off[k]..] to dense[dense_off[k]..].
+__global__ void pmx_compact_ops_kernel(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops,
+                                       const int64_t *dense_off, uint32_t *dense, long long n)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t *src = ops + ops_off[k];
+    uint32_t *dst = dense + dense_off[k];
+    const int m = nops[k];
+    for (int t = 0; t < m; ++t) dst[t] = src[t];
+}
+
+int pmx_launch_compact_ops(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops,
+                           const int64_t *dense_off, uint32_t *dense, long long n, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pmx_compact_ops_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream,
+                       ops, ops_off, nops, dense_off, dense, n);
+    hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
