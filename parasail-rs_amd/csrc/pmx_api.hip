@@ -864,6 +864,10 @@ extern "C" const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen,
     if (check_cfg(cfg)) return "invalid";
     if (fast_sw_eligible(cfg) && cfg->matrix->size <= PMX_MAX_FAST_MSIZE && max_qlen <= 2048 && max_rlen <= 60000)
         return "pmx_sw16_kernel";
+    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && cfg->want == 0 && cfg->width != 8 &&
+        cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && cfg->open >= cfg->extend && max_qlen < 2048 &&
+        cfg->matrix->size < PMX_MAX_FAST_MSIZE)
+        return "pmx_nwsg16_kernel";
     return "pmx_general_kernel";
 }
 
@@ -936,6 +940,12 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
             return 0;
         }
         // rc == 1: shape not covered by the fast kernel -> general kernel below
+    }
+    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && cfg->want == 0 && cfg->width != 8 &&
+        cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
+        const int rc = pmx_launch_nwsg16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, st, nullptr);
+        if (rc < 0) { set_err("nwsg16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
+        if (rc == 0) return 0;     // the host-side range proof makes overflow impossible: no promotion pass
     }
     if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
     void *bound = nullptr;

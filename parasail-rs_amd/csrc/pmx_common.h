@@ -29,6 +29,10 @@ struct PmxBatch {
 int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                     pmx_record_t *d_out, hipStream_t stream, const char **kernel_name);
 
+// Fast path: global / semi-global, score + end positions, biased packed lanes (pmx_nwsg16.hip).
+int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
+                      pmx_record_t *d_out, hipStream_t stream, const char **kernel_name);
+
 // ---- general kernel (all modes, stats, tables, rows/cols, trace, band) -------------------
 struct PmxGeneralArgs {
     // inputs

@@ -1,0 +1,410 @@
+// pmx_nwsg16.hip -- fast kernel for global (nw) and semi-global (sg, any free-end set) alignment,
+// score + end positions, many independent pairs per launch.  gfx950 only.
+//
+// Dispatch names `nw_striped_{16,sat,32,64}`, `sg[_q?][_d?]_striped_{16,sat,32,64}`
+// (/root/reference/src/aligner/mod.rs:289-331) when no stats / table / trace output is asked for.
+//
+// Same machine mapping as pmx_sw16.hip: G lanes per slot, two pairs per slot in the int16 halves of
+// every register, R query rows per lane in VGPRs, the reference streamed one column per step with a
+// one-step skew between neighbouring lanes (DPP), per-pair query profile in LDS.  Differences:
+//
+//   * Values are biased by 16384 so that negative scores are representable: the exact window is
+//     true value in [-15360, 15359] (bit patterns [1024, 31743], where v_pk_maximum3_f16 is an exact
+//     integer max3).  The host proves from lengths, gap penalties and matrix extremes that no cell can
+//     leave the window; otherwise the general 32-bit kernel is used.
+//   * The query is aligned to the BOTTOM of the G*R-row strip set, so its last row is always the last
+//     register of the last lane.  The P = G*R - qlen rows above it are *virtual rows*, the G-1 pad
+//     symbols in front of the reference are *virtual columns*.  Their profile scores are chosen so
+//     that the ordinary recurrences reproduce the boundary conditions exactly:
+//        penalised side  : score -inf, the F (resp. E) chain carries -(open + k*extend)
+//        free side (sg)  : score 0, the diagonal carries 0
+//        virtual x virtual : score 0 (an all-zero corner)
+//     (needs open >= extend, which the reference asks for: src/aligner/mod.rs:139-153).
+//     No lane ever needs a special case: lane 0's "row above" is the constant pair (H = 0, F = -inf).
+//   * Results are captured, not tracked: nw reads the last row at column rlen-1; sg keeps the first
+//     maximum of the last row (reference end free) and of the last column (query end free; last column
+//     wins only if strictly greater -- oracle/pmx_oracle.c states the rule).
+#include "pmx_common.h"
+#include <cstdlib>
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+
+#define PK(x)  __builtin_bit_cast(v2s, (int)(x))
+#define I32(x) __builtin_bit_cast(int, (x))
+
+#define NB 16384                       // bias
+#define NB2 ((NB << 16) | NB)
+#define NEGS ((short)-32768)           // "-inf" score: sets the sign bit of the biased sum
+
+__device__ __forceinline__ v2s n_addw(v2s a, v2s b)       // wrapping add (v_pk_add_u16)
+{
+    return __builtin_bit_cast(v2s, __builtin_bit_cast(v2us, a) + __builtin_bit_cast(v2us, b));
+}
+__device__ __forceinline__ v2s n_subus(v2s a, v2s b)      // v_pk_sub_u16 clamp
+{
+    return __builtin_bit_cast(v2s, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, b)));
+}
+__device__ __forceinline__ v2s n_max3(v2s a, v2s b, v2s c)
+{
+    int r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(I32(a)), "v"(I32(b)), "v"(I32(c)));
+    return PK(r);
+}
+__device__ __forceinline__ int n_bfi(int m, int a, int b)
+{
+    int r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+// per-half masks (0xFFFF / 0) on values below 32768
+__device__ __forceinline__ int m_lt(v2s a, v2s b) { const v2s sh = {15, 15}; return I32((a - b) >> sh); }      // a < b
+__device__ __forceinline__ int m_eq(v2s a, v2s b)
+{
+    const v2us one = {1, 1};
+    const v2us x = __builtin_bit_cast(v2us, I32(a) ^ I32(b));
+    return I32(__builtin_bit_cast(v2s, __builtin_elementwise_min(x, one) - one));
+}
+__device__ __forceinline__ int m_ult(v2s a, v2s b)        // unsigned a < b (a may be a "negative" column index)
+{
+    const v2us one = {1, 1}, zero = {0, 0};
+    const v2us d = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2us, b), __builtin_bit_cast(v2us, a));
+    return I32(__builtin_bit_cast(v2s, zero - __builtin_elementwise_min(d, one)));
+}
+
+template <int G>
+__device__ __forceinline__ int n_shift_up(int x, int neutral, int g)
+{
+    if (G <= 16) {
+        int r = __builtin_amdgcn_update_dpp(neutral, x, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+        if (G < 16) r = (g == 0) ? neutral : r;
+        return r;
+    } else {
+        int r = __builtin_amdgcn_update_dpp(neutral, x, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+        if (G < 64) r = (g == 0) ? neutral : r;
+        return r;
+    }
+}
+
+template <int G, int R>
+__global__ __launch_bounds__(64)
+void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
+                       const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
+                       long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
+                       int msize, int open, int ext, int RP, int q_shared,
+                       int col_pen /* H(i,-1) penalised */, int row_pen /* H(-1,j) penalised */,
+                       int s1_end /* query end free */, int s2_end /* reference end free */,
+                       pmx_record_t *__restrict__ out)
+{
+    static_assert(R % 2 == 0, "rows are stored two per dword");
+    constexpr int QP = G * R;
+    constexpr int QP2 = QP / 2;
+    constexpr int SLOTS = 64 / G;
+    constexpr int NP = 2 * SLOTS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int lane = threadIdx.x;
+    const int g = lane % G;
+    const int slot = lane / G;
+    const int MS1 = msize + 1;                      // + the pair's own pad-symbol row
+    const int PROF_STRIDE = MS1 * QP * 2;
+
+    // LDS carve: [prof NP][rsym NP*RP][mat][map 256][pair table NP*4 ints]
+    int16_t *prof = reinterpret_cast<int16_t *>(lds);
+    unsigned char *rsym = lds + NP * PROF_STRIDE;
+    int16_t *mat = reinterpret_cast<int16_t *>(rsym + NP * RP);
+    unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
+    int *ptab = reinterpret_cast<int *>(map + 256 + ((4 - ((msize * msize * 2) & 3)) & 3));
+
+    const long long pair0 = (long long)blockIdx.x * NP;
+
+    for (int i = lane; i < msize * msize; i += 64) mat[i] = gmat[i];
+    for (int i = lane; i < 256; i += 64) map[i] = gmap[i];
+    if (lane < NP) {
+        long long pi = pair0 + lane; if (pi >= n) pi = n - 1;
+        const long long qb = q_shared ? 0 : qoff[pi], rb = roff[pi];
+        ptab[4 * lane + 0] = (int)(qb - (q_shared ? 0 : qoff[pair0]));
+        ptab[4 * lane + 1] = q_shared ? q_shared : (int)(qoff[pi + 1] - qb);
+        ptab[4 * lane + 2] = (int)(rb - roff[pair0]);
+        ptab[4 * lane + 3] = (int)(roff[pi + 1] - rb);
+    }
+    __syncthreads();
+    const uint8_t *qbase = qbuf + (q_shared ? 0 : qoff[pair0]);
+    const uint8_t *rbase = rbuf + roff[pair0];
+
+    // ---- reference symbols, G-1 virtual columns in front, pad behind ---------------------
+    int max_rlen = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) max_rlen = max(max_rlen, ptab[4 * p + 3]);
+    constexpr int UB = 8;
+    for (int item0 = 0; item0 < NP * RP; item0 += 64 * UB) {
+        unsigned char raw[UB]; bool ok[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int item = item0 + u * 64 + lane;
+            const int p = min(item / RP, NP - 1), j = item - p * RP;
+            const int jj = j - (G - 1);
+            ok[u] = item < NP * RP && jj >= 0 && jj < ptab[4 * p + 3];
+            raw[u] = ok[u] ? rbase[ptab[4 * p + 2] + jj] : (unsigned char)0;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int item = item0 + u * 64 + lane;
+            if (item < NP * RP) rsym[item] = ok[u] ? map[raw[u]] : (unsigned char)msize;
+        }
+    }
+
+    // ---- extended profiles: P virtual rows on top of the qlen real rows --------------------
+    const int vrow_score = row_pen ? NEGS : 0;     // virtual row  x real symbol
+    const int vcol_score = col_pen ? NEGS : 0;     // real row     x pad symbol
+    constexpr int QITEMS = (NP * QP2 + 63) / 64;
+    constexpr int QB = QITEMS < 5 ? QITEMS : 5;
+    for (int it0 = 0; it0 < QITEMS; it0 += QB) {
+        unsigned char r0[QB], r1[QB]; bool v0[QB], v1[QB];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const int item = (it0 + u) * 64 + lane;
+            const int p = min(item / QP2, NP - 1), rp = item - p * QP2;
+            const int P = QP - ptab[4 * p + 1];
+            const uint8_t *qp = qbase + ptab[4 * p + 0];
+            v0[u] = item < NP * QP2 && 2 * rp >= P; v1[u] = item < NP * QP2 && 2 * rp + 1 >= P;
+            r0[u] = v0[u] ? qp[2 * rp - P] : (unsigned char)0;
+            r1[u] = v1[u] ? qp[2 * rp + 1 - P] : (unsigned char)0;
+        }
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const int item = (it0 + u) * 64 + lane;
+            if (it0 + u < QITEMS && item < NP * QP2) {
+                const int p = item / QP2, rp = item - p * QP2;
+                const int q0 = v0[u] ? map[r0[u]] : -1;
+                const int q1 = v1[u] ? map[r1[u]] : -1;
+                int *pp = reinterpret_cast<int *>(prof) + p * (PROF_STRIDE / 4) + rp;
+                for (int sym = 0; sym < msize; ++sym) {
+                    const int s0 = (q0 < 0) ? vrow_score : mat[q0 * msize + sym];
+                    const int s1 = (q1 < 0) ? vrow_score : mat[q1 * msize + sym];
+                    pp[sym * QP2] = (s0 & 0xFFFF) | (s1 << 16);
+                }
+                const int p0 = (q0 < 0) ? 0 : vcol_score, p1 = (q1 < 0) ? 0 : vcol_score;
+                pp[msize * QP2] = (p0 & 0xFFFF) | (p1 << 16);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane state ------------------------------------------------------------------
+    const int pA = 2 * slot, pB = 2 * slot + 1;
+    const unsigned char *profA = lds + pA * PROF_STRIDE + g * (R * 2);
+    const unsigned char *profB = lds + pB * PROF_STRIDE + g * (R * 2);
+    const unsigned char *rsA = rsym + pA * RP + (G - 1) - g;
+    const unsigned char *rsB = rsym + pB * RP + (G - 1) - g;
+    const int SYMSTRIDE = QP * 2;
+
+    const int PvA = QP - ptab[4 * pA + 1], PvB = QP - ptab[4 * pB + 1];   // virtual rows per half
+    const int rlA = ptab[4 * pA + 3], rlB = ptab[4 * pB + 3];
+    const v2s vOpen = PK((open & 0xFFFF) | (open << 16));
+    const v2s vExt = PK((ext & 0xFFFF) | (ext << 16));
+    const v2us one2 = {1, 1};
+
+    // H(row, -1): 0 for virtual rows and for a free query begin, -(open + i*ext) otherwise
+    auto left_h = [&](int erow, int P) -> int {
+        const int i = erow - P;
+        return NB + ((i >= 0 && col_pen) ? -(open + i * ext) : 0);
+    };
+    auto pack2 = [](int a, int b) -> int { return (a & 0xFFFF) | (b << 16); };
+
+    v2s HA[R], HB[R], E[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int hA = left_h(g * R + k, PvA), hB = left_h(g * R + k, PvB);
+        HA[k] = PK(pack2(hA, hB)); HB[k] = HA[k];
+        E[k] = PK(pack2(hA - open, hB - open));
+    }
+    int Hout = I32(HA[R - 1]);
+    // F flowing below the strip at virtual columns: -(open + i*ext) for a penalised real row below, else -open
+    auto below_f = [&](int erow, int P) -> int {
+        const int i = erow - P;
+        return NB + ((i >= 0 && col_pen) ? -(open + i * ext) : -open);
+    };
+    int Fout = pack2(below_f((g + 1) * R, PvA), below_f((g + 1) * R, PvB));
+    v2s diag0 = (g == 0) ? PK(NB2) : PK(pack2(left_h(g * R - 1, PvA), left_h(g * R - 1, PvB)));
+
+    const v2s rl1 = PK(pack2(rlA - 1, rlB - 1)), rlv = PK(pack2(rlA, rlB));
+    int jj = ((-g) & 0xFFFF) * 0x00010001;
+    int res = NB2;                         // nw / sg without free ends: H(qlen-1, rlen-1)
+    v2s bestrow = PK(0); int bestrowj = 0; // sg, reference end free: first max of the last row
+    v2s bestcol = PK(0); int bestcoli = 0; // sg, query end free: first max of the last column (extended row index)
+
+    auto load_scores = [&](int symA, int symB, int (&wa)[R / 2], int (&wb)[R / 2]) {
+        const int *sa = reinterpret_cast<const int *>(profA + symA * SYMSTRIDE);
+        const int *sb = reinterpret_cast<const int *>(profB + symB * SYMSTRIDE);
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
+    };
+    auto step = [&](const v2s (&Hold)[R], v2s (&Hnew)[R], const int (&wa)[R / 2], const int (&wb)[R / 2]) {
+        const int Hin = n_shift_up<G>(Hout, NB2, g);     // row above lane 0: H = 0
+        v2s F = PK(n_shift_up<G>(Fout, 0, g));           //                   F = -inf
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const v2s s = PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
+            const v2s d = (k == 0) ? diag0 : Hold[k - 1];
+            const v2s Tt = n_addw(d, s);
+            const v2s H = n_max3(Tt, E[k], F);
+            const v2s Ho = n_subus(H, vOpen);
+            E[k] = n_max3(n_subus(E[k], vExt), Ho, Ho);
+            F = n_max3(n_subus(F, vExt), Ho, Ho);
+            Hnew[k] = H;
+        }
+        diag0 = PK(Hin);
+        Hout = I32(Hnew[R - 1]);
+        Fout = I32(F);
+
+        // ---- captures ----
+        const v2s jv = PK(jj);
+        const int mLast = m_eq(jv, rl1);                  // this lane is at column rlen-1
+        res = n_bfi(mLast, Hout, res);
+        if (s2_end) {
+            const int imp = m_lt(bestrow, PK(Hout)) & m_ult(jv, rlv);
+            bestrow = PK(n_bfi(imp, Hout, I32(bestrow)));
+            bestrowj = n_bfi(imp, jj, bestrowj);
+        }
+        if (s1_end && __builtin_amdgcn_ballot_w64(mLast != 0) != 0) {
+            // last column of this strip: maximum over the REAL rows, smallest row first
+            const v2s Pv = PK(pack2(PvA, PvB));
+            v2s cm = PK(0); int krow = 0;
+            v2s vals[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int er = g * R + k;
+                const int mreal = ~m_lt(PK(pack2(er, er)), Pv);
+                vals[k] = PK(I32(Hnew[k]) & mreal);
+                cm = n_max3(cm, vals[k], vals[k]);
+            }
+#pragma unroll
+            for (int k = R - 1; k >= 0; --k) {
+                const int er = g * R + k;
+                krow = n_bfi(m_eq(vals[k], cm), pack2(er, er), krow);
+            }
+            const int imp = m_lt(bestcol, cm) & mLast;
+            bestcol = PK(n_bfi(imp, I32(cm), I32(bestcol)));
+            bestcoli = n_bfi(imp, krow, bestcoli);
+        }
+        jj = I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, jj) + one2));
+    };
+
+    const int T = (max_rlen + G - 1 + 1) & ~1;
+    int w0a[R / 2], w0b[R / 2], w1a[R / 2], w1b[R / 2];
+    load_scores(rsA[0], rsB[0], w0a, w0b);
+    int nsA = rsA[1], nsB = rsB[1];
+    for (int t = 0; t < T; t += 2) {
+        load_scores(nsA, nsB, w1a, w1b);
+        nsA = rsA[t + 2]; nsB = rsB[t + 2];
+        __builtin_amdgcn_sched_barrier(0);
+        step(HA, HB, w0a, w0b);
+        __builtin_amdgcn_sched_barrier(0);
+        load_scores(nsA, nsB, w0a, w0b);
+        nsA = rsA[t + 3]; nsB = rsB[t + 3];
+        __builtin_amdgcn_sched_barrier(0);
+        step(HB, HA, w1a, w1b);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- combine -----------------------------------------------------------------------
+    // last-column candidates: reduce (value desc, extended row asc) over the slot's lanes
+    unsigned keyA = ((unsigned)(I32(bestcol) & 0xFFFF) << 16) | (0xFFFFu - (unsigned)(bestcoli & 0xFFFF));
+    unsigned keyB = ((unsigned)((unsigned)I32(bestcol) >> 16) << 16) | (0xFFFFu - ((unsigned)bestcoli >> 16));
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) {
+        const unsigned oa = __shfl_xor(keyA, off, 64), ob = __shfl_xor(keyB, off, 64);
+        keyA = oa > keyA ? oa : keyA;
+        keyB = ob > keyB ? ob : keyB;
+    }
+    // the last lane of the slot owns the last row: corner value and last-row maximum
+    const int lastlane = slot * G + G - 1;
+    const int resL = __shfl(res, lastlane, 64);
+    const int browL = __shfl(I32(bestrow), lastlane, 64), browjL = __shfl(bestrowj, lastlane, 64);
+    if (g == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long pi = pair0 + 2 * slot + h;
+            if (pi < n) {
+                const int ql = ptab[4 * (2 * slot + h) + 1], rl = ptab[4 * (2 * slot + h) + 3];
+                const int P = QP - ql;
+                const int corner = ((h ? ((unsigned)resL >> 16) : (resL & 0xFFFF))) - NB;
+                pmx_record_t rec;
+                rec.flags = 0;
+                if (!s1_end && !s2_end) { rec.score = corner; rec.end_query = ql - 1; rec.end_ref = rl - 1; }
+                else {
+                    int best = -2147483647 - 1, ei = 0, ej = 0;
+                    if (s2_end) {
+                        best = (int)(h ? ((unsigned)browL >> 16) : (browL & 0xFFFF)) - NB;
+                        ei = ql - 1; ej = (int)(h ? ((unsigned)browjL >> 16) : (browjL & 0xFFFF));
+                    }
+                    if (s1_end) {
+                        const unsigned key = h ? keyB : keyA;
+                        const int cv = (int)(key >> 16) - NB;
+                        if (cv > best) { best = cv; ei = (int)(0xFFFFu - (key & 0xFFFFu)) - P; ej = rl - 1; }
+                    }
+                    rec.score = best; rec.end_query = ei; rec.end_ref = ej;
+                }
+                out[pi] = rec;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------ host side ----
+template <int G, int R>
+static int launch_nwsg(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
+                       pmx_record_t *d_out, hipStream_t stream)
+{
+    constexpr int QP = G * R, NP = 2 * (64 / G);
+    const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
+    const size_t lds = (size_t)NP * (m.msize + 1) * QP * 2 + (size_t)NP * RP +
+                       (size_t)m.msize * m.msize * 2 + 256 + 4 + (size_t)NP * 16;
+    if (lds > 160 * 1024) return 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_nwsg16_kernel<G, R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    const bool sg = mode == PMX_MODE_SG;
+    const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
+    const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
+    const long long blocks = (b.n + NP - 1) / NP;
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL((pmx_nwsg16_kernel<G, R>), dim3((unsigned)blocks), dim3(64), lds, stream,
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
+                       m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, d_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+// 0 launched, 1 not eligible (caller uses the general kernel), <0 HIP error
+int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
+                      pmx_record_t *d_out, hipStream_t stream, const char **kernel_name)
+{
+    if (getenv("PMX_NO_FAST_NWSG")) return 1;
+    if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
+    if (m.msize > PMX_MAX_FAST_MSIZE - 1) return 1;
+    if (open < ext || open < 0 || ext < 0) return 1;           // the virtual-row/column fixed points need open >= extend
+    if (b.max_rlen > 30000) return 1;
+    // exact window of the biased lanes: every H, E, F, H-open, E-ext and H(diag)+score stays inside
+    const long long lo = -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
+    const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);
+    if (lo < -15000 || hi > 15000) return 1;
+    const int q = b.max_qlen;
+#define TRYN(GG, RR, NAME)                                                      \
+    if (q <= (GG) * (RR) - 1) {                                                 \
+        int rc = launch_nwsg<GG, RR>(b, m, mode, sg_flags, open, ext, d_out, stream); \
+        if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; }       \
+    }
+    TRYN(16, 10, "pmx_nwsg16_kernel<16,10>")
+    TRYN(16, 16, "pmx_nwsg16_kernel<16,16>")
+    TRYN(32, 16, "pmx_nwsg16_kernel<32,16>")
+    TRYN(64, 16, "pmx_nwsg16_kernel<64,16>")
+    TRYN(64, 32, "pmx_nwsg16_kernel<64,32>")
+#undef TRYN
+    return 1;
+}

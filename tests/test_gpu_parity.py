@@ -242,6 +242,74 @@ def test_sw16_saturation_flag_and_promotion(pkg, orc):
         assert got["score"][0] == 40000 and got["score"][2] == 36000
 
 
+# ------------------------------------------------------ fast global / semi-global kernel ----
+def _nwsg_case(pkg, orc, mode, sg, qs, rs, open_, ext, pm, om, expect_kernel="pmx_nwsg16_kernel"):
+    import ctypes as C
+    b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext).solution_width(16)
+    [b.global_, b.semi_global][mode]()
+    if mode == 1 and sg is not None:
+        qg = [n for f, n in ((orc.S1_BEG, "prefix"), (orc.S1_END, "suffix")) if sg & f]
+        dg = [n for f, n in ((orc.S2_BEG, "prefix"), (orc.S2_END, "suffix")) if sg & f]
+        b.allow_query_gaps(qg).allow_ref_gaps(dg)
+    al = b.build()
+    cfg = al._config()
+    if expect_kernel:
+        assert pkg.lib.pmx_kernel_for(C.byref(cfg), max(map(len, qs)), max(map(len, rs))).decode() == expect_kernel
+    got = al.align_batch(qs, rs)
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    want = orc.align_batch(mode, qb, qo, rb, ro, open_, ext, om, sg_flags=sg if sg is not None else orc.SG_ALL, bits=16)
+    bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
+    assert len(bad) == 0, (mode, sg, open_, ext, bad[:5], got[bad[:5]], want[bad[:5]], [(qs[i], rs[i]) for i in bad[:2]])
+    assert (got["flags"] == 0).all()
+
+
+@pytest.mark.parametrize("gaps", [(5, 2), (0, 0), (1, 1), (11, 1), (3, 0)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_nwsg16_uniform_and_ragged(pkg, orc, mode, gaps):
+    rng = np.random.default_rng(3000 + 10 * mode + gaps[0])
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 600, 150, 150) + random_seqs(rng, 601, 1, 159)
+    rs = [mutate(rng, q, 0.1, 0.03) if i % 3 else random_seqs(rng, 1, 1, 250)[0] for i, q in enumerate(qs)]
+    _nwsg_case(pkg, orc, mode, None, qs, rs, gaps[0], gaps[1], pm, om)
+
+
+def test_nwsg16_sg_variants(pkg, orc):
+    rng = np.random.default_rng(3100)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 400, 5, 150)
+    rs = []
+    for q in qs:
+        core = mutate(rng, q, 0.1, 0.05)
+        rs.append(random_seqs(rng, 1, 1, 30)[0] + core + random_seqs(rng, 1, 1, 30)[0] if rng.random() < 0.5 else (core[4:-4] or core))
+    for sg in (orc.S1_BEG, orc.S1_END, orc.S2_BEG, orc.S2_END, orc.S1_BEG | orc.S1_END, orc.S2_BEG | orc.S2_END,
+               orc.S1_BEG | orc.S2_END, orc.S1_END | orc.S2_BEG, orc.S1_BEG | orc.S2_BEG, orc.S1_END | orc.S2_END,
+               orc.S1_BEG | orc.S1_END | orc.S2_BEG, orc.SG_ALL):
+        _nwsg_case(pkg, orc, 1, sg, qs, rs, 5, 2, pm, om)
+
+
+@pytest.mark.parametrize("maxlen", [159, 255, 511, 1000, 2000])
+def test_nwsg16_blosum62_all_instantiations(pkg, orc, maxlen):
+    rng = np.random.default_rng(3200 + maxlen)
+    pm = pkg.Matrix.from_name("blosum62")
+    om = orc.Matrix.from_file("tests/golden/blosum62.txt")
+    n = 100 if maxlen <= 511 else 30
+    qs = random_seqs(rng, n, max(1, maxlen // 3), maxlen, AA)
+    qs[0] = random_seqs(rng, 1, maxlen, maxlen, AA)[0]
+    rs = [mutate(rng, q, 0.3, 0.05, AA) if rng.random() < 0.7 else random_seqs(rng, 1, 10, maxlen, AA)[0] for q in qs]
+    for mode in (0, 1):
+        _nwsg_case(pkg, orc, mode, None, qs, rs, 11, 1, pm, om)
+
+
+def test_nwsg16_falls_back_outside_the_exact_window(pkg, orc):
+    """long sequences with large penalties leave the biased 16-bit window: the general kernel takes over"""
+    rng = np.random.default_rng(3300)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 20, 100, 150)
+    rs = random_seqs(rng, 20, 100, 150)
+    _nwsg_case(pkg, orc, 0, None, qs, rs, 60, 50, pm, om, expect_kernel=None)      # lo bound ~ -15000
+    _nwsg_case(pkg, orc, 0, None, qs, rs, 2, 5, pm, om, expect_kernel="pmx_general_kernel")   # open < extend
+
+
 # --------------------------------------------------------------------- general kernel ----
 def _check_general(pkg, orc, mode, sg, q, r, open_, ext, pm, om, width=0):
     want = orc.align(mode, q, r, open_, ext, om, sg_flags=sg if sg is not None else orc.SG_ALL, bits=width,
