@@ -1042,61 +1042,68 @@ extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_p
     return 0;
 }
 
-// CIGAR for a batch: general kernel with trace tables in HBM, then the on-device walk; only the
-// run-length ops come back to the host, which renders the text.
-extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
-                                     const uint8_t *qbuf, const int64_t *qoff,
-                                     const uint8_t *rbuf, const int64_t *roff,
-                                     pmx_record_t *out, char **cigar_buf, int64_t *cigar_off)
+// CIGAR for a batch.  Fast path: pmx_trace16 (4-bit trace in HBM, on-device walk); otherwise the general
+// kernel with byte trace tables and pmx_walk_kernel.  Only the run-length ops come back to the host, which
+// renders the text.  One chunk = one set of launches; chunks bound the trace scratch.
+static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
+                       const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
+                       pmx_record_t *out, std::string &text, int64_t *cigar_off /* n+1, cigar_off[0] preset */)
 {
-    if (check_cfg(cfg)) return -1;
-    if (!cigar_buf || !cigar_off) { set_err("null cigar output"); return -1; }
-    *cigar_buf = nullptr;
-    if (n <= 0) return 0;
-    if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
     int32_t mq = 0, mr = 0; bool bad = false;
     host_maxlens(n, qoff, &mq, &bad); host_maxlens(n, roff, &mr, &bad);
     if (bad || qoff[0] != 0 || roff[0] != 0) { set_err("bad offsets"); return -1; }
-    DevMat dm;
-    if (get_devmat(cfg->matrix, &dm)) return -1;
-    std::vector<int64_t> tab_off(n + 1), ops_off(n + 1);
-    tab_off[0] = 0; ops_off[0] = 0;
-    for (int64_t k = 0; k < n; ++k) {
-        const int64_t ql = qoff[k + 1] - qoff[k], rl = roff[k + 1] - roff[k];
-        tab_off[k + 1] = tab_off[k] + ql * rl;
-        ops_off[k + 1] = ops_off[k] + ql + rl + 1;
-    }
+    std::vector<int64_t> ops_off(n + 1);
+    ops_off[0] = 0;
+    for (int64_t k = 0; k < n; ++k) ops_off[k + 1] = ops_off[k] + (qoff[k + 1] - qoff[k]) + (roff[k + 1] - roff[k]) + 1;
     const size_t qbytes = (size_t)qoff[n], rbytes = (size_t)roff[n];
-    DevBuf<uint8_t> dq, dr; DevBuf<int64_t> dqo, dro, dto, doo; DevBuf<pmx_record_t> drec;
-    struct { int8_t *p; } dtrace; struct { uint32_t *p; } dops; DevBuf<int32_t> dnops, dbeg;   // trace/ops: pooled scratch
-    dq.alloc(qbytes); dr.alloc(rbytes); dqo.alloc(n + 1); dro.alloc(n + 1); dto.alloc(n + 1); doo.alloc(n + 1);
+    DevBuf<uint8_t> dq, dr; DevBuf<int64_t> dqo, dro, doo; DevBuf<pmx_record_t> drec; DevBuf<int32_t> dnops, dbeg;
+    dq.alloc(qbytes); dr.alloc(rbytes); dqo.alloc(n + 1); dro.alloc(n + 1); doo.alloc(n + 1);
     drec.alloc(n); dnops.alloc(n); dbeg.alloc(2 * n);
-    if (scratch_reserve((size_t)tab_off[n], (void **)&dtrace.p, SCR_TRACE)) return -1;
-    if (scratch_reserve((size_t)ops_off[n] * sizeof(uint32_t), (void **)&dops.p, SCR_OPS)) return -1;
+    uint32_t *dops = nullptr;
+    if (scratch_reserve((size_t)ops_off[n] * sizeof(uint32_t), (void **)&dops, SCR_OPS)) return -1;
     HIP_OR_RET(hipMemcpy(dq.p, qbuf, qbytes, hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dqo.p, qoff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
-    HIP_OR_RET(hipMemcpy(dto.p, tab_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(doo.p, ops_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
-    void *bound = nullptr;
-    const size_t stride = (size_t)8 * mr;
-    if (scratch_reserve((size_t)n * stride * sizeof(int32_t), &bound)) return -1;
-    PmxGeneralArgs a; memset(&a, 0, sizeof a);
-    a.qbuf = dq.p; a.qoff = dqo.p; a.rbuf = dr.p; a.roff = dro.p; a.n = n; a.max_rlen = mr;
-    a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
-    a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
-    a.bits = cfg->width;
-    a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
-    a.rec = drec.p; a.tab_off = dto.p; a.trace_table = dtrace.p;
-    int rc = pmx_launch_general(a, false, nullptr);
-    if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
-    PmxWalkArgs w; memset(&w, 0, sizeof w);
-    w.qbuf = dq.p; w.qoff = dqo.p; w.rbuf = dr.p; w.roff = dro.p; w.n = n;
-    w.mapper = dm.d.mapper; w.mode = cfg->mode; w.trace_table = dtrace.p; w.tab_off = dto.p; w.rec = drec.p;
-    w.ops = dops.p; w.ops_off = doo.p; w.nops = dnops.p; w.beg = dbeg.p;
-    rc = pmx_launch_walk(w, nullptr);
-    if (rc) { set_err("walk kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+
+    PmxBatch b = {dq.p, dqo.p, dr.p, dro.p, n, mq, mr, 0};
+    int variant = 0, Tmax = 0; size_t tbytes = 0;
+    int rc;
+    if (cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&
+        pmx_trace16_plan(b, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes) == 0) {
+        uint32_t *tbuf = nullptr;
+        if (scratch_reserve(tbytes, (void **)&tbuf, SCR_TRACE)) return -1;
+        rc = pmx_launch_trace16(variant, b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, drec.p, tbuf, Tmax,
+                                dops, doo.p, dnops.p, dbeg.p, nullptr);
+        if (rc) { set_err("trace16 launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    } else {
+        std::vector<int64_t> tab_off(n + 1);
+        tab_off[0] = 0;
+        for (int64_t k = 0; k < n; ++k) tab_off[k + 1] = tab_off[k] + (qoff[k + 1] - qoff[k]) * (roff[k + 1] - roff[k]);
+        DevBuf<int64_t> dto; dto.alloc(n + 1);
+        HIP_OR_RET(hipMemcpy(dto.p, tab_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+        int8_t *dtrace = nullptr; void *bound = nullptr;
+        if (scratch_reserve((size_t)tab_off[n], (void **)&dtrace, SCR_TRACE)) return -1;
+        const size_t stride = (size_t)8 * mr;
+        if (scratch_reserve((size_t)n * stride * sizeof(int32_t), &bound)) return -1;
+        PmxGeneralArgs a; memset(&a, 0, sizeof a);
+        a.qbuf = dq.p; a.qoff = dqo.p; a.rbuf = dr.p; a.roff = dro.p; a.n = n; a.max_rlen = mr;
+        a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
+        a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
+        a.bits = cfg->width;
+        a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
+        a.rec = drec.p; a.tab_off = dto.p; a.trace_table = dtrace;
+        rc = pmx_launch_general(a, false, nullptr);
+        if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+        PmxWalkArgs w; memset(&w, 0, sizeof w);
+        w.qbuf = dq.p; w.qoff = dqo.p; w.rbuf = dr.p; w.roff = dro.p; w.n = n;
+        w.mapper = dm.d.mapper; w.mode = cfg->mode; w.trace_table = dtrace; w.tab_off = dto.p; w.rec = drec.p;
+        w.ops = dops; w.ops_off = doo.p; w.nops = dnops.p; w.beg = dbeg.p;
+        rc = pmx_launch_walk(w, nullptr);
+        if (rc) { set_err("walk kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+        HIP_OR_RET(hipDeviceSynchronize());      // dto is released on scope exit
+    }
     // only the runs actually produced come back: nops first, then a dense copy of the ops
     std::vector<int32_t> nops(n);
     HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
@@ -1107,13 +1114,10 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
     DevBuf<int64_t> ddo; DevBuf<uint32_t> ddense;
     ddo.alloc(n + 1); ddense.alloc((size_t)dense_off[n]);
     HIP_OR_RET(hipMemcpy(ddo.p, dense_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
-    rc = pmx_launch_compact_ops(dops.p, doo.p, dnops.p, ddo.p, ddense.p, n, nullptr);
+    rc = pmx_launch_compact_ops(dops, doo.p, dnops.p, ddo.p, ddense.p, n, nullptr);
     if (rc) { set_err("compaction kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
     std::vector<uint32_t> ops((size_t)dense_off[n] + 1);
     HIP_OR_RET(hipMemcpy(ops.data(), ddense.p, sizeof(uint32_t) * (size_t)dense_off[n], hipMemcpyDeviceToHost));
-    std::string text;
-    text.reserve((size_t)dense_off[n] * 4);
-    cigar_off[0] = 0;
     char num[16];
     for (int64_t k = 0; k < n; ++k) {
         for (int64_t t = dense_off[k]; t < dense_off[k + 1]; ++t) {
@@ -1124,6 +1128,40 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
             text.push_back(BAM_OPS[o & 0xF]);
         }
         cigar_off[k + 1] = (int64_t)text.size();
+    }
+    return 0;
+}
+
+extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
+                                     const uint8_t *qbuf, const int64_t *qoff,
+                                     const uint8_t *rbuf, const int64_t *roff,
+                                     pmx_record_t *out, char **cigar_buf, int64_t *cigar_off)
+{
+    if (check_cfg(cfg)) return -1;
+    if (!cigar_buf || !cigar_off) { set_err("null cigar output"); return -1; }
+    *cigar_buf = nullptr;
+    if (n <= 0) return 0;
+    if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
+    if (qoff[0] != 0 || roff[0] != 0) { set_err("offset arrays must start at 0"); return -1; }
+    DevMat dm;
+    if (get_devmat(cfg->matrix, &dm)) return -1;
+    std::string text;
+    cigar_off[0] = 0;
+    // chunks keep the per-launch trace scratch below ~16 GiB (a pair needs at most ~(qlen+64)*(rlen+64)/2 bytes)
+    int64_t c0 = 0;
+    while (c0 < n) {
+        int64_t c1 = c0; double bytes = 0;
+        while (c1 < n && (c1 == c0 || bytes < 16e9)) {
+            bytes += 1.0 * (double)(qoff[c1 + 1] - qoff[c1] + 64) * (double)(roff[c1 + 1] - roff[c1] + 64);
+            ++c1;
+        }
+        const int64_t m = c1 - c0;
+        std::vector<int64_t> qo(m + 1), ro(m + 1);
+        for (int64_t k = 0; k <= m; ++k) { qo[k] = qoff[c0 + k] - qoff[c0]; ro[k] = roff[c0 + k] - roff[c0]; }
+        const int rc = cigar_chunk(cfg, dm, m, qbuf + qoff[c0], qo.data(), rbuf + roff[c0], ro.data(),
+                                   out + c0, text, cigar_off + c0);
+        if (rc) return rc;
+        c0 = c1;
     }
     *cigar_buf = (char *)malloc(text.size() + 1);
     if (!*cigar_buf) { set_err("out of memory"); return -1; }

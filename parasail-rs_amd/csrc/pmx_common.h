@@ -33,6 +33,13 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
 int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                       pmx_record_t *d_out, hipStream_t stream, const char **kernel_name);
 
+// Fast path with traceback (pmx_trace16.hip): 4-bit trace in HBM + on-device walk -> run-length ops.
+int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
+                     int *variant, int *Tmax, size_t *trace_bytes);
+int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
+                       pmx_record_t *d_out, uint32_t *tbuf, int Tmax,
+                       uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream);
+
 // ---- general kernel (all modes, stats, tables, rows/cols, trace, band) -------------------
 struct PmxGeneralArgs {
     // inputs

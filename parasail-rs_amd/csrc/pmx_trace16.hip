@@ -1,0 +1,396 @@
+// pmx_trace16.hip -- fast kernel for global / semi-global alignment WITH traceback, for the batch
+// CIGAR entry (BASELINE config 4: `sg_trace_striped_16` + CIGAR, /root/reference/src/alignment/mod.rs:
+// 390-419 for the single-pair counterpart).  gfx950 only.
+//
+// Mapping: the strip-systolic layout of pmx_nwsg16.hip (G lanes per pair, R query rows per lane in
+// VGPRs, one reference column per step, DPP skew, LDS query profile, virtual rows / columns that
+// reproduce the boundary conditions), but ONE pair per slot and unpacked 16-bit lanes:
+//
+//   * All DP arithmetic is full-rate 32-bit-encoded VOP2 on the low 16 bits of a VGPR
+//     (v_add_u16 / v_sub_u16 / v_max_u16, values biased by 32768): 8 instructions per cell.
+//   * The four traceback decisions of a cell are four v_cmp_lt_u16 (VOPC -> VCC), each followed by
+//     v_addc_co_u32 plane, plane, plane, vcc  -- "shift the lane's trace word left and insert the
+//     bit" in one VOP2.  After R = 8 rows the word holds eight 4-bit cells:
+//        bit3 ND  : H came from E or F            (T < H)
+//        bit2 NDL : not from F                    (F < H)      [ND && !NDL -> DEL, ND && NDL -> INS]
+//        bit1 EO  : E of the NEXT column opened   (E - ext < H - open)
+//        bit0 FO  : F of the NEXT row opened      (F - ext < H - open)
+//     Ties resolve exactly as in the oracle: diag, then F, then E; "open" only when strictly greater.
+//   * One coalesced dword store per lane and step: 4 bits per cell in HBM instead of the reference
+//     layout's byte per cell (which only the single-pair API still materialises).
+//   * pmx_walk16_kernel (one lane per pair) walks the nibbles from the captured end position and
+//     emits run-length BAM ops.
+#include "pmx_common.h"
+#include <cstdlib>
+
+#define TB 32768                 // bias of the u16 lanes
+#define TNEG (-16384)            // finite "-inf": loses against every value of the exact window
+#define OP_I 1u
+#define OP_D 2u
+#define OP_EQ 7u
+#define OP_X 8u
+#define OP_FOR_INS_STATE OP_D    // E / horizontal / consumes a reference character
+#define OP_FOR_DEL_STATE OP_I    // F / vertical   / consumes a query character
+
+__device__ __forceinline__ unsigned a16(unsigned a, unsigned b) { unsigned r; asm("v_add_u16_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned s16(unsigned a, unsigned b) { unsigned r; asm("v_sub_u16_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned m16(unsigned a, unsigned b) { unsigned r; asm("v_max_u16_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// plane = plane * 2 + (a < b)   (unsigned 16-bit compare)
+__device__ __forceinline__ void push_lt(unsigned &plane, unsigned a, unsigned b)
+{
+    asm("v_cmp_lt_u16_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(plane) : "v"(a), "v"(b) : "vcc");
+}
+
+template <int G>
+__device__ __forceinline__ unsigned t_shift_up(unsigned x, unsigned neutral, int g)
+{
+    if (G <= 16) {
+        int r = __builtin_amdgcn_update_dpp((int)neutral, (int)x, 0x111, 0xF, 0xF, false);
+        if (G < 16) r = (g == 0) ? (int)neutral : r;
+        return (unsigned)r;
+    } else {
+        int r = __builtin_amdgcn_update_dpp((int)neutral, (int)x, 0x138, 0xF, 0xF, false);
+        if (G < 64) r = (g == 0) ? (int)neutral : r;
+        return (unsigned)r;
+    }
+}
+
+template <int G, int R>
+__global__ __launch_bounds__(64)
+void pmx_trace16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
+                        const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
+                        long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
+                        int msize, int open, int ext, int RP, int Tmax,
+                        int col_pen, int row_pen, int s1_end, int s2_end,
+                        pmx_record_t *__restrict__ out, uint32_t *__restrict__ tbuf)
+{
+    static_assert(R == 8 || R == 16, "one trace dword per 8 rows");
+    constexpr int QP = G * R;
+    constexpr int NP = 64 / G;             // pairs per wave
+    constexpr int TW = R / 8;              // trace dwords per lane and step
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int lane = threadIdx.x;
+    const int g = lane % G;
+    const int slot = lane / G;
+    const int MS1 = msize + 1;
+    const int PROF_STRIDE = MS1 * QP * 2;
+
+    int16_t *prof = reinterpret_cast<int16_t *>(lds);
+    unsigned char *rsym = lds + NP * PROF_STRIDE;
+    int16_t *mat = reinterpret_cast<int16_t *>(rsym + NP * RP);
+    unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
+    int *ptab = reinterpret_cast<int *>(map + 256 + ((4 - ((msize * msize * 2) & 3)) & 3));
+
+    const long long pair0 = (long long)blockIdx.x * NP;
+    for (int i = lane; i < msize * msize; i += 64) mat[i] = gmat[i];
+    for (int i = lane; i < 256; i += 64) map[i] = gmap[i];
+    if (lane < NP) {
+        long long pi = pair0 + lane; if (pi >= n) pi = n - 1;
+        const long long qb = qoff[pi], rb = roff[pi];
+        ptab[4 * lane + 0] = (int)(qb - qoff[pair0]);
+        ptab[4 * lane + 1] = (int)(qoff[pi + 1] - qb);
+        ptab[4 * lane + 2] = (int)(rb - roff[pair0]);
+        ptab[4 * lane + 3] = (int)(roff[pi + 1] - rb);
+    }
+    __syncthreads();
+    const uint8_t *qbase = qbuf + qoff[pair0];
+    const uint8_t *rbase = rbuf + roff[pair0];
+
+    int max_rlen = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) max_rlen = max(max_rlen, ptab[4 * p + 3]);
+
+    // reference symbols: G-1 virtual columns in front, pad symbol behind
+    for (int p = 0; p < NP; ++p) {
+        const int rl = ptab[4 * p + 3];
+        const uint8_t *rp = rbase + ptab[4 * p + 2];
+        for (int j0 = 0; j0 < RP; j0 += 64 * 4) {
+            unsigned char raw[4]; bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 64 + lane, jj = j - (G - 1);
+                ok[u] = j < RP && jj >= 0 && jj < rl;
+                raw[u] = ok[u] ? rp[jj] : (unsigned char)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 64 + lane;
+                if (j < RP) rsym[p * RP + j] = ok[u] ? map[raw[u]] : (unsigned char)msize;
+            }
+        }
+    }
+    // extended profile: P virtual rows on top, then the qlen real rows
+    const int vrow_score = row_pen ? TNEG : 0, vcol_score = col_pen ? TNEG : 0;
+    for (int p = 0; p < NP; ++p) {
+        const int P = QP - ptab[4 * p + 1];
+        const uint8_t *qp = qbase + ptab[4 * p + 0];
+        int16_t *pp = prof + p * (PROF_STRIDE / 2);
+        for (int er0 = 0; er0 < QP; er0 += 64 * 4) {
+            int qs[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int er = er0 + u * 64 + lane;
+                qs[u] = (er < QP && er >= P) ? (int)qp[er - P] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int er = er0 + u * 64 + lane;
+                if (er < QP) {
+                    const int q0 = qs[u] < 0 ? -1 : map[qs[u]];
+                    for (int sym = 0; sym < msize; ++sym)
+                        pp[sym * QP + er] = (int16_t)((q0 < 0) ? vrow_score : mat[q0 * msize + sym]);
+                    pp[msize * QP + er] = (int16_t)((q0 < 0) ? 0 : vcol_score);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane state --------------------------------------------------------------------
+    const unsigned short *profL = reinterpret_cast<const unsigned short *>(lds + slot * PROF_STRIDE) + g * R;
+    const unsigned char *rs = rsym + slot * RP + (G - 1) - g;
+    const int ql = ptab[4 * slot + 1], rl = ptab[4 * slot + 3];
+    const int P = QP - ql;
+    const unsigned vOpen = (unsigned)open, vExt = (unsigned)ext;
+
+    auto left_h = [&](int er) -> unsigned {
+        const int i = er - P;
+        return (unsigned)(TB + ((i >= 0 && col_pen) ? -(open + i * ext) : 0));
+    };
+    unsigned HA[R], HB[R], E[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { HA[k] = left_h(g * R + k); HB[k] = HA[k]; E[k] = HA[k] - vOpen; }
+    unsigned Hout = HA[R - 1];
+    unsigned Fout;
+    {
+        const int i = (g + 1) * R - P;
+        Fout = (unsigned)(TB + ((i >= 0 && col_pen) ? -(open + i * ext) : -open));
+    }
+    unsigned diag0 = (g == 0) ? (unsigned)TB : left_h(g * R - 1);
+
+    int res = TB, bestrow = 0, bestrowj = 0, bestcol = 0, bestcoli = 0;
+    uint32_t *tw = tbuf + ((size_t)blockIdx.x * Tmax) * (64 * TW) + lane * TW;
+
+    auto load_scores = [&](int sym, unsigned (&w)[R]) {
+        const unsigned short *sp = profL + sym * QP;
+#pragma unroll
+        for (int k = 0; k < R; ++k) w[k] = sp[k];
+    };
+    auto step = [&](const unsigned (&Hold)[R], unsigned (&Hnew)[R], const unsigned (&w)[R], int t) {
+        const unsigned Hin = t_shift_up<G>(Hout, (unsigned)TB, g);
+        unsigned F = t_shift_up<G>(Fout, (unsigned)(TB + TNEG), g);
+        unsigned plane[TW];
+#pragma unroll
+        for (int x = 0; x < TW; ++x) plane[x] = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const unsigned d = (k == 0) ? diag0 : Hold[k - 1];
+            const unsigned Tt = a16(d, w[k]);
+            const unsigned H = m16(m16(Tt, E[k]), F);
+            push_lt(plane[k / 8], Tt, H);          // ND
+            push_lt(plane[k / 8], F, H);           // NDL
+            const unsigned Ho = s16(H, vOpen);
+            const unsigned Ee = s16(E[k], vExt), Fe = s16(F, vExt);
+            push_lt(plane[k / 8], Ee, Ho);         // EO (next column)
+            push_lt(plane[k / 8], Fe, Ho);         // FO (next row)
+            E[k] = m16(Ee, Ho);
+            F = m16(Fe, Ho);
+            Hnew[k] = H;
+        }
+        diag0 = Hin;
+        Hout = Hnew[R - 1];
+        Fout = F;
+#pragma unroll
+        for (int x = 0; x < TW; ++x) tw[(size_t)t * (64 * TW) + x] = plane[x];
+
+        // ---- captures ----
+        const int jcol = t - g;
+        const int hl = (int)(Hout & 0xFFFF);
+        if (jcol == rl - 1) res = hl;
+        if (s2_end && jcol >= 0 && jcol < rl && hl > bestrow) { bestrow = hl; bestrowj = jcol; }
+        if (s1_end && jcol == rl - 1) {
+            int cm = 0, cr = 0;
+#pragma unroll
+            for (int k = R - 1; k >= 0; --k) {
+                const int er = g * R + k;
+                const int v = (er >= P) ? (int)(Hnew[k] & 0xFFFF) : 0;
+                if (v >= cm) { cm = v; cr = er; }          // descending k with >= : smallest row among equals
+            }
+            if (cm > bestcol) { bestcol = cm; bestcoli = cr; }
+        }
+    };
+
+    const int T = (max_rlen + G - 1 + 1) & ~1;
+    unsigned w0[R], w1[R];
+    load_scores(rs[0], w0);
+    int ns = rs[1];
+    for (int t = 0; t < T; t += 2) {
+        load_scores(ns, w1);
+        ns = rs[t + 2];
+        __builtin_amdgcn_sched_barrier(0);
+        step(HA, HB, w0, t);
+        __builtin_amdgcn_sched_barrier(0);
+        load_scores(ns, w0);
+        ns = rs[t + 3];
+        __builtin_amdgcn_sched_barrier(0);
+        step(HB, HA, w1, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- combine (same rules as pmx_nwsg16.hip / the oracle) ---------------------------------
+    unsigned key = ((unsigned)bestcol << 16) | (0xFFFFu - (unsigned)bestcoli);
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) {
+        const unsigned o = __shfl_xor(key, off, 64);
+        key = o > key ? o : key;
+    }
+    const int lastlane = slot * G + G - 1;
+    const int resL = __shfl(res, lastlane, 64), browL = __shfl(bestrow, lastlane, 64), browjL = __shfl(bestrowj, lastlane, 64);
+    if (g == 0) {
+        const long long pi = pair0 + slot;
+        if (pi < n) {
+            pmx_record_t rec; rec.flags = 0;
+            if (!s1_end && !s2_end) { rec.score = resL - TB; rec.end_query = ql - 1; rec.end_ref = rl - 1; }
+            else {
+                int best = -2147483647 - 1, ei = 0, ej = 0;
+                if (s2_end) { best = browL - TB; ei = ql - 1; ej = browjL; }
+                if (s1_end) {
+                    const int cv = (int)(key >> 16) - TB;
+                    if (cv > best) { best = cv; ei = (int)(0xFFFFu - (key & 0xFFFFu)) - P; ej = rl - 1; }
+                }
+                rec.score = best; rec.end_query = ei; rec.end_ref = ej;
+            }
+            out[pi] = rec;
+        }
+    }
+}
+
+// ---- walk over the 4-bit trace ---------------------------------------------------------------
+template <int G, int R>
+__global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
+                                  long long n, const uint8_t *mapper, int mode, int Tmax,
+                                  const uint32_t *tbuf, const pmx_record_t *recs,
+                                  uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg)
+{
+    constexpr int QP = G * R, NP = 64 / G, TW = R / 8;
+    const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= n) return;
+    const long long qb = qoff[pair], rb = roff[pair];
+    const int ql = (int)(qoff[pair + 1] - qb), rl = (int)(roff[pair + 1] - rb);
+    const uint8_t *q = qbuf + qb, *r = rbuf + rb;
+    const long long block = pair / NP; const int slot = (int)(pair % NP);
+    const uint32_t *tb = tbuf + (size_t)block * Tmax * (64 * TW);
+    const int P = QP - ql;
+    auto nib = [&](int i, int j) -> unsigned {         // i >= -1 (row -1 = last virtual row), j >= 0
+        const int er = i + P, g = er / R, k = er % R;
+        const uint32_t w = tb[(size_t)(j + g) * (64 * TW) + (slot * G + g) * TW + (k / 8)];
+        return (w >> (28 - 4 * (k % 8))) & 0xFu;
+    };
+    uint32_t *o = ops + ops_off[pair];
+    const pmx_record_t rec = recs[pair];
+    int i = rec.end_query, j = rec.end_ref, cnt = 0;
+    uint32_t cur_op = 0, cur_len = 0;
+    auto emit = [&](uint32_t op) {
+        if (op == cur_op) ++cur_len;
+        else { if (cur_len) o[cnt++] = (cur_len << 4) | cur_op; cur_op = op; cur_len = 1; }
+    };
+    if (mode == PMX_MODE_SG) {
+        if (i + 1 == ql) { for (int k = rl - 1; k > j; --k) emit(OP_FOR_INS_STATE); }
+        else if (j + 1 == rl) { for (int k = ql - 1; k > i; --k) emit(OP_FOR_DEL_STATE); }
+    }
+    int where = 0;   // 0 DIAG, 1 INS, 2 DEL
+    while (i >= 0 || j >= 0) {
+        if (i < 0) { emit(OP_FOR_INS_STATE); --j; continue; }
+        if (j < 0) { emit(OP_FOR_DEL_STATE); --i; continue; }
+        if (where == 0) {
+            const unsigned t = nib(i, j);
+            if (!(t & 8u)) { emit(mapper[q[i]] == mapper[r[j]] ? OP_EQ : OP_X); --i; --j; }
+            else if (!(t & 4u)) where = 2;
+            else where = 1;
+        } else if (where == 1) {
+            emit(OP_FOR_INS_STATE);
+            if (j > 0 && (nib(i, j - 1) & 2u)) where = 0;
+            --j;
+        } else {
+            emit(OP_FOR_DEL_STATE);
+            if (nib(i - 1, j) & 1u) where = 0;
+            --i;
+        }
+    }
+    if (cur_len) o[cnt++] = (cur_len << 4) | cur_op;
+    for (int k = 0; k < cnt / 2; ++k) { const uint32_t tmp = o[k]; o[k] = o[cnt - 1 - k]; o[cnt - 1 - k] = tmp; }
+    nops[pair] = cnt;
+    beg[2 * pair] = i + 1; beg[2 * pair + 1] = j + 1;
+}
+
+// ------------------------------------------------------------------------ host side ----
+template <int G, int R>
+static int launch_trace(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
+                        pmx_record_t *d_out, uint32_t *tbuf, int Tmax,
+                        uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream)
+{
+    constexpr int QP = G * R, NP = 64 / G;
+    const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
+    const size_t lds = (size_t)NP * (m.msize + 1) * QP * 2 + (size_t)NP * RP +
+                       (size_t)m.msize * m.msize * 2 + 256 + 4 + (size_t)NP * 16;
+    if (lds > 160 * 1024) return 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_trace16_kernel<G, R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -(int)e;
+        attr_done = true;
+    }
+    const bool sg = mode == PMX_MODE_SG;
+    const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
+    const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
+    const long long blocks = (b.n + NP - 1) / NP;
+    hipLaunchKernelGGL((pmx_trace16_kernel<G, R>), dim3((unsigned)blocks), dim3(64), lds, stream,
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
+                       m.msize, open, ext, RP, Tmax, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, d_out, tbuf);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return -(int)e;
+    hipLaunchKernelGGL((pmx_walk16_kernel<G, R>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream,
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, mode, Tmax,
+                       (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+// Picks the instantiation; *trace_bytes / *Tmax tell the caller how much trace scratch to provide
+// (call once with tbuf == nullptr to size it).  Returns 1 when the batch is not eligible.
+int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
+                     int *variant, int *Tmax, size_t *trace_bytes)
+{
+    if (getenv("PMX_NO_FAST_TRACE")) return 1;
+    if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
+    if (m.msize > PMX_MAX_FAST_MSIZE - 1) return 1;
+    if (open < ext || open < 0 || ext < 0 || open > 4096) return 1;
+    if (b.max_rlen > 30000 || b.q_shared) return 1;
+    const long long lo = -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
+    const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);
+    if (lo < -15000 || hi > 15000) return 1;
+    int G, R;
+    if (b.max_qlen <= 32 * 8 - 1) { *variant = 0; G = 32; R = 8; }
+    else if (b.max_qlen <= 64 * 8 - 1) { *variant = 1; G = 64; R = 8; }
+    else if (b.max_qlen <= 64 * 16 - 1) { *variant = 2; G = 64; R = 16; }
+    else return 1;
+    const int NP = 64 / G;
+    *Tmax = (b.max_rlen + G - 1 + 1) & ~1;
+    const long long blocks = (b.n + NP - 1) / NP;
+    *trace_bytes = (size_t)blocks * (size_t)*Tmax * 64 * (R / 8) * sizeof(uint32_t);
+    return 0;
+}
+
+int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
+                       pmx_record_t *d_out, uint32_t *tbuf, int Tmax,
+                       uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream)
+{
+    switch (variant) {
+    case 0: return launch_trace<32, 8>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stream);
+    case 1: return launch_trace<64, 8>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stream);
+    case 2: return launch_trace<64, 16>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stream);
+    }
+    return 1;
+}

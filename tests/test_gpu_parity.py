@@ -481,6 +481,57 @@ def test_batch_cigar_semi_global(pkg, orc):
             assert cig[k] == orc.cigar(w), (mode, k)
 
 
+def _cigar_case(pkg, orc, mode, sg, qs, rs, open_, ext, pm, om):
+    b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext).solution_width(16).use_trace()
+    [b.global_, b.semi_global, b.local][mode]()
+    if mode == 1 and sg is not None:
+        qg = [n for f, n in ((orc.S1_BEG, "prefix"), (orc.S1_END, "suffix")) if sg & f]
+        dg = [n for f, n in ((orc.S2_BEG, "prefix"), (orc.S2_END, "suffix")) if sg & f]
+        b.allow_query_gaps(qg).allow_ref_gaps(dg)
+    rec, cig = b.build().align_batch_cigar(qs, rs)
+    for k in range(len(qs)):
+        w = orc.align(mode, qs[k], rs[k], open_, ext, om, sg_flags=sg if sg is not None else orc.SG_ALL, trace=True)
+        assert (rec["score"][k], rec["end_query"][k], rec["end_ref"][k]) == (w.score, w.end_query, w.end_ref), (mode, sg, k)
+        assert cig[k] == orc.cigar(w), (mode, sg, k, qs[k], rs[k], cig[k], orc.cigar(w))
+
+
+@pytest.mark.parametrize("gaps", [(5, 2), (0, 0), (1, 1), (11, 1), (3, 0)])
+def test_trace16_cigar_gap_models(pkg, orc, gaps):
+    """fast traceback kernel (4-bit trace + device walk) against the oracle's byte trace + walk"""
+    rng = np.random.default_rng(4000 + gaps[0])
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 120, 1, 250)
+    rs = [mutate(rng, q, 0.12, 0.06) if i % 4 else random_seqs(rng, 1, 1, 300)[0] for i, q in enumerate(qs)]
+    for mode in (0, 1):
+        _cigar_case(pkg, orc, mode, None, qs, rs, gaps[0], gaps[1], pm, om)
+
+
+def test_trace16_cigar_sg_variants_and_sizes(pkg, orc):
+    rng = np.random.default_rng(4100)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 60, 20, 250)
+    rs = [random_seqs(rng, 1, 0, 25)[0] + mutate(rng, q, 0.1, 0.05) + random_seqs(rng, 1, 0, 25)[0] for q in qs]
+    for sg in (orc.S1_BEG, orc.S1_END, orc.S2_BEG, orc.S2_END, orc.S1_BEG | orc.S1_END, orc.S2_BEG | orc.S2_END,
+               orc.S1_END | orc.S2_BEG, orc.S1_BEG | orc.S2_END):
+        _cigar_case(pkg, orc, 1, sg, qs, rs, 5, 2, pm, om)
+    for maxlen in (255, 400, 511, 700, 1023, 1100):      # <32,8>, <64,8>, <64,16>, general kernel
+        q2 = random_seqs(rng, 12, maxlen // 2, maxlen)
+        q2[0] = random_seqs(rng, 1, maxlen, maxlen)[0]
+        r2 = [mutate(rng, q, 0.1, 0.03) for q in q2]
+        _cigar_case(pkg, orc, 1, None, q2, r2, 5, 2, pm, om)
+        _cigar_case(pkg, orc, 0, None, q2, r2, 5, 2, pm, om)
+
+
+def test_trace16_cigar_blosum62(pkg, orc):
+    rng = np.random.default_rng(4200)
+    pm = pkg.Matrix.from_name("blosum62")
+    om = orc.Matrix.from_file("tests/golden/blosum62.txt")
+    qs = random_seqs(rng, 60, 30, 250, AA)
+    rs = [mutate(rng, q, 0.3, 0.06, AA) for q in qs]
+    for mode in (0, 1):
+        _cigar_case(pkg, orc, mode, None, qs, rs, 11, 1, pm, om)
+
+
 def test_pssm_single_pair(pkg, orc):
     pm = pkg.Matrix.from_name("blosum62")
     om = orc.Matrix.from_file("tests/golden/blosum62.txt")
