@@ -33,6 +33,10 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
 int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                       pmx_record_t *d_out, hipStream_t stream, const char **kernel_name);
 
+// Fast path with statistics (pmx_stats16.hip): matches / similar / length travel with H, E, F.
+int pmx_launch_stats16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
+                       pmx_record_t *d_out, pmx_stats_t *d_stats, hipStream_t stream, const char **kernel_name);
+
 // Fast path with traceback (pmx_trace16.hip): 4-bit trace in HBM + on-device walk -> run-length ops.
 int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
                      int *variant, int *Tmax, size_t *trace_bytes);

@@ -481,6 +481,64 @@ def test_batch_cigar_semi_global(pkg, orc):
             assert cig[k] == orc.cigar(w), (mode, k)
 
 
+def _stats_case(pkg, orc, mode, sg, qs, rs, open_, ext, pm, om, shared_query=None):
+    b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext).solution_width(16)
+    [b.global_, b.semi_global][mode]()
+    if mode == 1 and sg is not None:
+        qg = [n for f, n in ((orc.S1_BEG, "prefix"), (orc.S1_END, "suffix")) if sg & f]
+        dg = [n for f, n in ((orc.S2_BEG, "prefix"), (orc.S2_END, "suffix")) if sg & f]
+        b.allow_query_gaps(qg).allow_ref_gaps(dg)
+    if shared_query is not None:
+        b.profile(pkg.Profile.new(shared_query, True, pm))
+        rec, st = b.build().align_batch([], rs)
+        qs = [shared_query] * len(rs)
+    else:
+        rec, st = b.use_stats().build().align_batch(qs, rs)
+    for k in range(len(rs)):
+        w = orc.align(mode, qs[k], rs[k], open_, ext, om, sg_flags=sg if sg is not None else orc.SG_ALL, stats=True)
+        got = (rec["score"][k], rec["end_query"][k], rec["end_ref"][k], st["matches"][k], st["similar"][k], st["length"][k])
+        want = (w.score, w.end_query, w.end_ref, w.matches, w.similar, w.length)
+        assert got == want, (mode, sg, k, got, want, qs[k], rs[k])
+
+
+@pytest.mark.parametrize("gaps", [(5, 2), (1, 1), (11, 1), (3, 3)])
+def test_stats16_gap_models(pkg, orc, gaps):
+    rng = np.random.default_rng(5000 + gaps[0])
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 150, 1, 160)
+    rs = [mutate(rng, q, 0.12, 0.06) if i % 4 else random_seqs(rng, 1, 1, 300)[0] for i, q in enumerate(qs)]
+    for mode in (0, 1):
+        _stats_case(pkg, orc, mode, None, qs, rs, gaps[0], gaps[1], pm, om)
+
+
+def test_stats16_sg_variants_and_sizes(pkg, orc):
+    rng = np.random.default_rng(5100)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 60, 20, 150)
+    rs = [random_seqs(rng, 1, 0, 25)[0] + mutate(rng, q, 0.1, 0.05) + random_seqs(rng, 1, 0, 25)[0] for q in qs]
+    for sg in (orc.S1_BEG, orc.S1_END, orc.S2_BEG, orc.S2_END, orc.S1_BEG | orc.S1_END, orc.S2_BEG | orc.S2_END,
+               orc.S1_END | orc.S2_BEG, orc.S1_BEG | orc.S2_END):
+        _stats_case(pkg, orc, 1, sg, qs, rs, 5, 2, pm, om)
+    for maxlen in (160, 256, 320, 512, 1024, 1100):      # one per instantiation, last one -> general kernel
+        q2 = random_seqs(rng, 10, maxlen // 2, maxlen)
+        q2[0] = random_seqs(rng, 1, maxlen, maxlen)[0]
+        r2 = [mutate(rng, q, 0.1, 0.03) for q in q2]
+        _stats_case(pkg, orc, 0, None, q2, r2, 5, 2, pm, om)
+        _stats_case(pkg, orc, 1, None, q2, r2, 5, 2, pm, om)
+
+
+def test_stats16_shared_query_blosum62(pkg, orc):
+    """config 3 shape through the 4-wave shared-profile variant"""
+    rng = np.random.default_rng(5200)
+    pm = pkg.Matrix.from_name("blosum62")
+    om = orc.Matrix.from_file("tests/golden/blosum62.txt")
+    q = random_seqs(rng, 1, 300, 300, AA)[0]
+    rs = [mutate(rng, q, 0.4, 0.05, AA) + random_seqs(rng, 1, 0, 300, AA)[0] for _ in range(41)]
+    rs += random_seqs(rng, 9, 800, 1500, AA)
+    for mode in (0, 1):
+        _stats_case(pkg, orc, mode, None, None, rs, 11, 1, pm, om, shared_query=q)
+
+
 def _cigar_case(pkg, orc, mode, sg, qs, rs, open_, ext, pm, om):
     b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext).solution_width(16).use_trace()
     [b.global_, b.semi_global, b.local][mode]()
