@@ -868,6 +868,10 @@ extern "C" const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen,
         cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && cfg->open >= cfg->extend && max_qlen < 2048 &&
         cfg->matrix->size < PMX_MAX_FAST_MSIZE)
         return "pmx_nwsg16_kernel";
+    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && cfg->want == PMX_WANT_STATS && cfg->width != 8 &&
+        cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && cfg->open >= cfg->extend && cfg->extend >= 1 &&
+        max_qlen <= 1024 && cfg->matrix->size < PMX_MAX_FAST_MSIZE)
+        return "pmx_stats16_kernel";
     return "pmx_general_kernel";
 }
 

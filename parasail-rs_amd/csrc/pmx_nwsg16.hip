@@ -402,6 +402,7 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
     }
     TRYN(16, 10, "pmx_nwsg16_kernel<16,10>")
     TRYN(16, 16, "pmx_nwsg16_kernel<16,16>")
+    TRYN(32, 10, "pmx_nwsg16_kernel<32,10>")
     TRYN(32, 16, "pmx_nwsg16_kernel<32,16>")
     TRYN(64, 16, "pmx_nwsg16_kernel<64,16>")
     TRYN(64, 32, "pmx_nwsg16_kernel<64,32>")

@@ -399,6 +399,7 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
     }
     TRY(16, 10, "pmx_sw16_kernel<16,10>")
     TRY(16, 16, "pmx_sw16_kernel<16,16>")
+    TRY(32, 10, "pmx_sw16_kernel<32,10>")
     TRY(32, 16, "pmx_sw16_kernel<32,16>")
     TRY(64, 16, "pmx_sw16_kernel<64,16>")
     TRY(64, 32, "pmx_sw16_kernel<64,32>")
