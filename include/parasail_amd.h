@@ -224,6 +224,8 @@ void parasail_profile_free(parasail_profile_t *profile);
 
 #define PMX_WANT_STATS 1     /* matches / similar / length per pair */
 #define PMX_WANT_CIGAR 2     /* on-device traceback, CIGAR text per pair */
+#define PMX_WANT_SORTED 4    /* lengths are ragged: let the engine process pairs in length order (records stay in
+                                input order).  The host-buffer entries set it themselves when it pays. */
 
 #define PMX_FLAG_SATURATED 1 /* result record flag: the requested width overflowed */
 #define PMX_FLAG_RERUN 2     /* internal: a fast kernel left its exact range; never visible to callers */

@@ -855,7 +855,7 @@ static int check_cfg(const pmx_config_t *cfg)
 
 static bool fast_sw_eligible(const pmx_config_t *cfg)
 {
-    return cfg->mode == PMX_MODE_SW && cfg->want == 0 && cfg->width != 8 &&
+    return cfg->mode == PMX_MODE_SW && (cfg->want & ~PMX_WANT_SORTED) == 0 && cfg->width != 8 &&
            cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE;
 }
 
@@ -864,11 +864,11 @@ extern "C" const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen,
     if (check_cfg(cfg)) return "invalid";
     if (fast_sw_eligible(cfg) && cfg->matrix->size <= PMX_MAX_FAST_MSIZE && max_qlen <= 2048 && max_rlen <= 60000)
         return "pmx_sw16_kernel";
-    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && cfg->want == 0 && cfg->width != 8 &&
+    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && (cfg->want & ~PMX_WANT_SORTED) == 0 && cfg->width != 8 &&
         cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && cfg->open >= cfg->extend && max_qlen < 2048 &&
         cfg->matrix->size < PMX_MAX_FAST_MSIZE)
         return "pmx_nwsg16_kernel";
-    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && cfg->want == PMX_WANT_STATS && cfg->width != 8 &&
+    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && (cfg->want & ~PMX_WANT_SORTED) == PMX_WANT_STATS && cfg->width != 8 &&
         cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && cfg->open >= cfg->extend && cfg->extend >= 1 &&
         max_qlen <= 1024 && cfg->matrix->size < PMX_MAX_FAST_MSIZE)
         return "pmx_stats16_kernel";
@@ -877,7 +877,7 @@ extern "C" const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen,
 
 // grow-only per-(thread,device) scratch for the general kernel's band boundary rows
 struct Scratch { void *p = nullptr; size_t cap = 0; int dev = -1; };
-enum { SCR_BOUND = 0, SCR_TRACE = 1, SCR_OPS = 2, SCR_SLOTS = 3 };
+enum { SCR_BOUND = 0, SCR_TRACE = 1, SCR_OPS = 2, SCR_SORT = 3, SCR_SLOTS = 4 };
 static thread_local Scratch g_scratch_pool[SCR_SLOTS];
 static int scratch_reserve(size_t bytes, void **out, int slot = SCR_BOUND)
 {
@@ -908,7 +908,14 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
     DevMat dm;
     if (get_devmat(cfg->matrix, &dm)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, max_qlen, max_rlen, q_shared};
+    PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, max_qlen, max_rlen, q_shared, nullptr};
+    const int want = cfg->want & ~PMX_WANT_SORTED;
+    if ((cfg->want & PMX_WANT_SORTED) && n >= 64 && n < (1LL << 32)) {
+        void *scr = nullptr;
+        if (scratch_reserve(pmx_sort_scratch_bytes(n), &scr, SCR_SORT)) return -1;
+        const int rc = pmx_build_length_perm(d_roff, n, scr, &b.perm, st);
+        if (rc < 0) { set_err("length sort failed (%d)", rc); return rc; }
+    }
     if (fast_sw_eligible(cfg)) {
         const int rc = pmx_launch_sw16(b, dm.d, cfg->open, cfg->extend, d_out, st, nullptr);
         if (rc < 0) { set_err("sw16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
@@ -945,13 +952,13 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         }
         // rc == 1: shape not covered by the fast kernel -> general kernel below
     }
-    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && cfg->want == PMX_WANT_STATS && cfg->width != 8 &&
+    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && want == PMX_WANT_STATS && cfg->width != 8 &&
         cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
         const int rc = pmx_launch_stats16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, d_stats_out, st, nullptr);
         if (rc < 0) { set_err("stats16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
         if (rc == 0) return 0;
     }
-    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && cfg->want == 0 && cfg->width != 8 &&
+    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && want == 0 && cfg->width != 8 &&
         cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
         const int rc = pmx_launch_nwsg16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, st, nullptr);
         if (rc < 0) { set_err("nwsg16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
@@ -969,7 +976,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
     a.bits = cfg->width;
     a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
     a.rec = d_out; a.stats = d_stats_out;
-    const int rc = pmx_launch_general(a, (cfg->want & PMX_WANT_STATS) != 0, st);
+    const int rc = pmx_launch_general(a, (want & PMX_WANT_STATS) != 0, st);
     if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
     return 0;
 }
@@ -983,15 +990,24 @@ extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
     return run_batch_device(cfg, n, d_qbuf, d_qoff, 0, d_rbuf, d_roff, max_qlen, max_rlen, d_out, d_stats_out, stream);
 }
 
-static void host_maxlens(int64_t n, const int64_t *off, int32_t *mx, bool *bad)
+static void host_maxlens(int64_t n, const int64_t *off, int32_t *mx, bool *bad, int32_t *mn = nullptr)
 {
-    int64_t m = 0;
+    int64_t m = 0, lo = INT32_MAX;
     for (int64_t k = 0; k < n; ++k) {
         const int64_t l = off[k + 1] - off[k];
         if (l <= 0 || l > INT32_MAX) *bad = true;
         m = l > m ? l : m;
+        lo = l < lo ? l : lo;
     }
     *mx = (int32_t)m;
+    if (mn) *mn = (int32_t)lo;
+}
+// ragged reference lengths: worth a length-sorted processing order
+static pmx_config_t with_sort_hint(const pmx_config_t *cfg, int32_t min_rlen, int32_t max_rlen, int64_t n)
+{
+    pmx_config_t c = *cfg;
+    if (n >= 256 && (long long)min_rlen * 5 < (long long)max_rlen * 4) c.want |= PMX_WANT_SORTED;
+    return c;
 }
 
 extern "C" int pmx_align_batch(const pmx_config_t *cfg, int64_t n,
@@ -1002,9 +1018,11 @@ extern "C" int pmx_align_batch(const pmx_config_t *cfg, int64_t n,
     if (check_cfg(cfg)) return -1;
     if (n <= 0) return 0;
     if (!qbuf || !qoff || !rbuf || !roff || !out) { set_err("null buffer"); return -1; }
-    int32_t mq = 0, mr = 0; bool bad = false;
-    host_maxlens(n, qoff, &mq, &bad); host_maxlens(n, roff, &mr, &bad);
+    int32_t mq = 0, mr = 0, mnr = 0; bool bad = false;
+    host_maxlens(n, qoff, &mq, &bad); host_maxlens(n, roff, &mr, &bad, &mnr);
     if (bad) { set_err("every sequence must have length >= 1"); return -1; }
+    const pmx_config_t cfg_s = with_sort_hint(cfg, mnr, mr, n);
+    cfg = &cfg_s;
     const size_t qbytes = (size_t)(qoff[n] - qoff[0]), rbytes = (size_t)(roff[n] - roff[0]);
     if (qoff[0] != 0 || roff[0] != 0) { set_err("offset arrays must start at 0"); return -1; }
     DevBuf<uint8_t> dq, dr; DevBuf<int64_t> dqo, dro; DevBuf<pmx_record_t> drec; DevBuf<pmx_stats_t> dst;
@@ -1031,9 +1049,11 @@ extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_p
     if (n <= 0) return 0;
     if (profile->matrix != cfg->matrix) { set_err("profile was built with a different matrix"); return -1; }
     if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
-    int32_t mr = 0; bool bad = false;
-    host_maxlens(n, roff, &mr, &bad);
+    int32_t mr = 0, mnr = 0; bool bad = false;
+    host_maxlens(n, roff, &mr, &bad, &mnr);
     if (bad || roff[0] != 0) { set_err("bad reference offsets"); return -1; }
+    const pmx_config_t cfg_s = with_sort_hint(cfg, mnr, mr, n);
+    cfg = &cfg_s;
     const bool stats = (cfg->want & PMX_WANT_STATS) != 0;
     if (stats && !stats_out) { set_err("stats requested without a stats buffer"); return -1; }
     DevMat dm;
@@ -1077,7 +1097,7 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
     HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(doo.p, ops_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
 
-    PmxBatch b = {dq.p, dqo.p, dr.p, dro.p, n, mq, mr, 0};
+    PmxBatch b = {dq.p, dqo.p, dr.p, dro.p, n, mq, mr, 0, nullptr};
     int variant = 0, Tmax = 0; size_t tbytes = 0;
     int rc;
     if (cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&

@@ -21,6 +21,7 @@ struct PmxBatch {
     int64_t n;
     int max_qlen, max_rlen;
     int q_shared;            // > 0: one shared query of that many bytes at qbuf (profile arm), qoff unused
+    const unsigned *perm;    // optional processing order (pmx_sort.hip): position -> pair index
 };
 
 // Fast path: local alignment, score + end positions, packed int16 lanes.
@@ -28,6 +29,10 @@ struct PmxBatch {
 // through to the general kernel), <0 on a HIP error.
 int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                     pmx_record_t *d_out, hipStream_t stream, const char **kernel_name);
+
+// Length-sorted processing order for ragged batches (pmx_sort.hip).
+size_t pmx_sort_scratch_bytes(long long n);
+int pmx_build_length_perm(const int64_t *d_roff, long long n, void *scratch, const unsigned **perm_out, hipStream_t stream);
 
 // Fast path: global / semi-global, score + end positions, biased packed lanes (pmx_nwsg16.hip).
 int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,

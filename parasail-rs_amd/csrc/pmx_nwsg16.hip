@@ -94,7 +94,8 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
                        int msize, int open, int ext, int RP, int q_shared,
                        int col_pen /* H(i,-1) penalised */, int row_pen /* H(-1,j) penalised */,
                        int s1_end /* query end free */, int s2_end /* reference end free */,
-                       pmx_record_t *__restrict__ out)
+                       const unsigned *__restrict__ perm,
+                     pmx_record_t *__restrict__ out)
 {
     static_assert(R % 2 == 0, "rows are stored two per dword");
     constexpr int QP = G * R;
@@ -114,28 +115,30 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
     unsigned char *rsym = lds + NP * PROF_STRIDE;
     int16_t *mat = reinterpret_cast<int16_t *>(rsym + NP * RP);
     unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
-    int *ptab = reinterpret_cast<int *>(map + 256 + ((4 - ((msize * msize * 2) & 3)) & 3));
+    long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));   // per pair: q offset, qlen, r offset, rlen, pair index
 
     const long long pair0 = (long long)blockIdx.x * NP;
 
     for (int i = lane; i < msize * msize; i += 64) mat[i] = gmat[i];
     for (int i = lane; i < 256; i += 64) map[i] = gmap[i];
     if (lane < NP) {
-        long long pi = pair0 + lane; if (pi >= n) pi = n - 1;
+        long long pos = pair0 + lane; if (pos >= n) pos = n - 1;
+        const long long pi = perm ? (long long)perm[pos] : pos;
         const long long qb = q_shared ? 0 : qoff[pi], rb = roff[pi];
-        ptab[4 * lane + 0] = (int)(qb - (q_shared ? 0 : qoff[pair0]));
-        ptab[4 * lane + 1] = q_shared ? q_shared : (int)(qoff[pi + 1] - qb);
-        ptab[4 * lane + 2] = (int)(rb - roff[pair0]);
-        ptab[4 * lane + 3] = (int)(roff[pi + 1] - rb);
+        ptab[5 * lane + 0] = qb;
+        ptab[5 * lane + 1] = q_shared ? q_shared : (qoff[pi + 1] - qb);
+        ptab[5 * lane + 2] = rb;
+        ptab[5 * lane + 3] = roff[pi + 1] - rb;
+        ptab[5 * lane + 4] = (pair0 + lane < n) ? pi : -1;
     }
     __syncthreads();
-    const uint8_t *qbase = qbuf + (q_shared ? 0 : qoff[pair0]);
-    const uint8_t *rbase = rbuf + roff[pair0];
+    const uint8_t *qbase = qbuf;
+    const uint8_t *rbase = rbuf;
 
     // ---- reference symbols, G-1 virtual columns in front, pad behind ---------------------
     int max_rlen = 0;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) max_rlen = max(max_rlen, ptab[4 * p + 3]);
+    for (int p = 0; p < NP; ++p) max_rlen = max(max_rlen, (int)ptab[5 * p + 3]);
     constexpr int UB = 8;
     for (int item0 = 0; item0 < NP * RP; item0 += 64 * UB) {
         unsigned char raw[UB]; bool ok[UB];
@@ -144,8 +147,8 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
             const int item = item0 + u * 64 + lane;
             const int p = min(item / RP, NP - 1), j = item - p * RP;
             const int jj = j - (G - 1);
-            ok[u] = item < NP * RP && jj >= 0 && jj < ptab[4 * p + 3];
-            raw[u] = ok[u] ? rbase[ptab[4 * p + 2] + jj] : (unsigned char)0;
+            ok[u] = item < NP * RP && jj >= 0 && jj < (int)ptab[5 * p + 3];
+            raw[u] = ok[u] ? rbase[ptab[5 * p + 2] + jj] : (unsigned char)0;
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -165,8 +168,8 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
         for (int u = 0; u < QB; ++u) {
             const int item = (it0 + u) * 64 + lane;
             const int p = min(item / QP2, NP - 1), rp = item - p * QP2;
-            const int P = QP - ptab[4 * p + 1];
-            const uint8_t *qp = qbase + ptab[4 * p + 0];
+            const int P = QP - (int)ptab[5 * p + 1];
+            const uint8_t *qp = qbase + ptab[5 * p + 0];
             v0[u] = item < NP * QP2 && 2 * rp >= P; v1[u] = item < NP * QP2 && 2 * rp + 1 >= P;
             r0[u] = v0[u] ? qp[2 * rp - P] : (unsigned char)0;
             r1[u] = v1[u] ? qp[2 * rp + 1 - P] : (unsigned char)0;
@@ -199,8 +202,8 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
     const unsigned char *rsB = rsym + pB * RP + (G - 1) - g;
     const int SYMSTRIDE = QP * 2;
 
-    const int PvA = QP - ptab[4 * pA + 1], PvB = QP - ptab[4 * pB + 1];   // virtual rows per half
-    const int rlA = ptab[4 * pA + 3], rlB = ptab[4 * pB + 3];
+    const int PvA = QP - (int)ptab[5 * pA + 1], PvB = QP - (int)ptab[5 * pB + 1];   // virtual rows per half
+    const int rlA = (int)ptab[5 * pA + 3], rlB = (int)ptab[5 * pB + 3];
     const v2s vOpen = PK((open & 0xFFFF) | (open << 16));
     const v2s vExt = PK((ext & 0xFFFF) | (ext << 16));
     const v2us one2 = {1, 1};
@@ -325,9 +328,9 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
     if (g == 0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const long long pi = pair0 + 2 * slot + h;
-            if (pi < n) {
-                const int ql = ptab[4 * (2 * slot + h) + 1], rl = ptab[4 * (2 * slot + h) + 3];
+            const long long pi = ptab[5 * (2 * slot + h) + 4];
+            if (pi >= 0) {
+                const int ql = (int)ptab[5 * (2 * slot + h) + 1], rl = (int)ptab[5 * (2 * slot + h) + 3];
                 const int P = QP - ql;
                 const int corner = ((h ? ((unsigned)resL >> 16) : (resL & 0xFFFF))) - NB;
                 pmx_record_t rec;
@@ -360,7 +363,7 @@ static int launch_nwsg(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
     constexpr int QP = G * R, NP = 2 * (64 / G);
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
     const size_t lds = (size_t)NP * (m.msize + 1) * QP * 2 + (size_t)NP * RP +
-                       (size_t)m.msize * m.msize * 2 + 256 + 4 + (size_t)NP * 16;
+                       (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
     if (lds > 160 * 1024) return 1;
     static bool attr_done = false;
     if (!attr_done) {
@@ -376,7 +379,7 @@ static int launch_nwsg(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
     if (blocks <= 0) return 0;
     hipLaunchKernelGGL((pmx_nwsg16_kernel<G, R>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
-                       m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, d_out);
+                       m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, b.perm, d_out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

@@ -1,0 +1,40 @@
+// pmx_sort.hip -- length-sorted processing order for ragged batches (BASELINE config 5: references of
+// 0.5-5 kbp against one query).  A slot runs for max(rlen A, rlen B) steps and a wave for the maximum
+// over its slots, so pairs of similar length are grouped: keys = reference lengths, values = pair
+// indices, rocPRIM radix sort (descending: the longest pairs start first, which also trims the tail
+// of the launch).  Kernels read pair perm[position] and write their record to out[perm[position]],
+// so results stay in input order.
+#include <cstring>
+#include <cstdlib>
+#include "pmx_common.h"
+#include <rocprim/rocprim.hpp>
+
+__global__ void pmx_len_keys_kernel(const int64_t *roff, long long n, unsigned *keys, unsigned *vals)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = (unsigned)(roff[i + 1] - roff[i]); vals[i] = (unsigned)i; }
+}
+
+// scratch layout (caller provides `scratch` of pmx_sort_scratch_bytes(n) bytes):
+//   [keys_in n][keys_out n][vals_in n][perm n][rocprim temp]
+size_t pmx_sort_scratch_bytes(long long n)
+{
+    size_t temp = 0;
+    unsigned *nul = nullptr;
+    (void)rocprim::radix_sort_pairs_desc(nullptr, temp, nul, nul, nul, nul, (size_t)n, 0, 32, nullptr);
+    return (size_t)n * 4 * sizeof(unsigned) + ((temp + 255) & ~(size_t)255) + 256;
+}
+
+int pmx_build_length_perm(const int64_t *d_roff, long long n, void *scratch, const unsigned **perm_out, hipStream_t stream)
+{
+    if (n <= 0 || n >= (1LL << 32)) return 1;
+    unsigned *keys_in = (unsigned *)scratch, *keys_out = keys_in + n, *vals_in = keys_out + n, *perm = vals_in + n;
+    void *temp = (void *)(((uintptr_t)(perm + n) + 255) & ~(uintptr_t)255);
+    size_t temp_bytes = 0;
+    (void)rocprim::radix_sort_pairs_desc(nullptr, temp_bytes, keys_in, keys_out, vals_in, perm, (size_t)n, 0, 32, stream);
+    hipLaunchKernelGGL(pmx_len_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_roff, n, keys_in, vals_in);
+    hipError_t e = rocprim::radix_sort_pairs_desc(temp, temp_bytes, keys_in, keys_out, vals_in, perm, (size_t)n, 0, 32, stream);
+    if (e != hipSuccess) return -(int)e;
+    *perm_out = perm;
+    return 0;
+}

@@ -50,6 +50,7 @@ void pmx_stats16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
                         long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
                         int msize, int open, int ext, int RP, int q_shared,
                         int col_pen, int row_pen, int s1_end, int s2_end,
+                        const unsigned *__restrict__ perm,
                         pmx_record_t *__restrict__ out, pmx_stats_t *__restrict__ stats_out)
 {
     constexpr int QP = G * R;
@@ -68,26 +69,28 @@ void pmx_stats16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     unsigned char *rsym = reinterpret_cast<unsigned char *>(psc + NPROF * MS1 * QP);
     int16_t *mat = reinterpret_cast<int16_t *>(rsym + NP * RP);
     unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
-    int *ptab = reinterpret_cast<int *>(map + 256 + ((4 - ((msize * msize * 2) & 3)) & 3));
+    long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));
 
     const long long pair0 = (long long)blockIdx.x * NP;
     for (int i = tid; i < msize * msize; i += 64 * WAVES) mat[i] = gmat[i];
     for (int i = tid; i < 256; i += 64 * WAVES) map[i] = gmap[i];
     if (tid < NP) {
-        long long pi = pair0 + tid; if (pi >= n) pi = n - 1;
+        long long pos = pair0 + tid; if (pos >= n) pos = n - 1;
+        const long long pi = perm ? (long long)perm[pos] : pos;
         const long long qb = q_shared ? 0 : qoff[pi], rb = roff[pi];
-        ptab[4 * tid + 0] = (int)(qb - (q_shared ? 0 : qoff[pair0]));
-        ptab[4 * tid + 1] = q_shared ? q_shared : (int)(qoff[pi + 1] - qb);
-        ptab[4 * tid + 2] = (int)(rb - roff[pair0]);
-        ptab[4 * tid + 3] = (int)(roff[pi + 1] - rb);
+        ptab[5 * tid + 0] = qb;
+        ptab[5 * tid + 1] = q_shared ? q_shared : (qoff[pi + 1] - qb);
+        ptab[5 * tid + 2] = rb;
+        ptab[5 * tid + 3] = roff[pi + 1] - rb;
+        ptab[5 * tid + 4] = (pair0 + tid < n) ? pi : -1;
     }
     __syncthreads();
-    const uint8_t *qbase = qbuf + (q_shared ? 0 : qoff[pair0]);
-    const uint8_t *rbase = rbuf + roff[pair0];
+    const uint8_t *qbase = qbuf;
+    const uint8_t *rbase = rbuf;
 
     for (int p = 0; p < NP; ++p) {
-        const int rlp = ptab[4 * p + 3];
-        const uint8_t *rp = rbase + ptab[4 * p + 2];
+        const int rlp = (int)ptab[5 * p + 3];
+        const uint8_t *rp = rbase + ptab[5 * p + 2];
         for (int j0 = 0; j0 < RP; j0 += 64 * WAVES * 4) {
             unsigned char raw[4]; bool ok[4];
 #pragma unroll
@@ -105,8 +108,8 @@ void pmx_stats16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     }
     const int vcol_score = col_pen ? SNEG : 0;
     for (int p = 0; p < NPROF; ++p) {
-        const int qlp = ptab[4 * p + 1];
-        const uint8_t *qp = qbase + ptab[4 * p + 0];
+        const int qlp = (int)ptab[5 * p + 1];
+        const uint8_t *qp = qbase + ptab[5 * p + 0];
         for (int er = tid; er < QP; er += 64 * WAVES) {
             const int q0 = (er < qlp) ? (int)map[qp[er]] : -1;
             for (int sym = 0; sym < msize; ++sym) {
@@ -125,7 +128,7 @@ void pmx_stats16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     const unsigned short *scL = psc + pslot * MS1 * QP + g * R;
     const unsigned *incL = pinc + pslot * MS1 * QP + g * R;
     const unsigned char *rs = rsym + slot * RP + (G - 1) - g;
-    const int ql = ptab[4 * slot + 1], rl = ptab[4 * slot + 3];
+    const int ql = (int)ptab[5 * slot + 1], rl = (int)ptab[5 * slot + 3];
     const unsigned vOpen = (unsigned)open, vExt = (unsigned)ext;
     const int gL = (ql - 1) / R, kL = (ql - 1) % R;       // owner of the last query row
 
@@ -214,7 +217,7 @@ void pmx_stats16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 
     int max_rlen = 0;
 #pragma unroll
-    for (int p = 0; p < NPW; ++p) max_rlen = max(max_rlen, ptab[4 * (wave * NPW + p) + 3]);
+    for (int p = 0; p < NPW; ++p) max_rlen = max(max_rlen, (int)ptab[5 * (wave * NPW + p) + 3]);
     const int T = (max_rlen + G - 1 + 1) & ~1;
     unsigned w0[R], wi0[R], w1[R], wi1[R];
     load_scores(rs[0], w0, wi0);
@@ -254,8 +257,8 @@ void pmx_stats16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     br.H = __shfl(brow.H, ll, 64); br.i = __shfl(brow.i, ll, 64); br.j = __shfl(brow.j, ll, 64);
     br.MS = __shfl(brow.MS, ll, 64); br.L = __shfl(brow.L, ll, 64);
     if (g == 0) {
-        const long long pi = pair0 + slot;
-        if (pi < n) {
+        const long long pi = ptab[5 * slot + 4];
+        if (pi >= 0) {
             SCand res;
             if (!s1_end && !s2_end) res = co;
             else {
@@ -280,7 +283,7 @@ static int launch_stats(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
     const int nprof = b.q_shared ? 1 : NP;
     const size_t lds = (size_t)nprof * (m.msize + 1) * QP * 6 + (size_t)NP * RP +
-                       (size_t)m.msize * m.msize * 2 + 256 + 4 + (size_t)NP * 16;
+                       (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
     if (lds > 160 * 1024) return 1;
     static bool attr_done = false;
     if (!attr_done) {
@@ -296,7 +299,7 @@ static int launch_stats(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     hipLaunchKernelGGL((pmx_stats16_kernel<G, R, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                        m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0,
-                       d_out, d_stats);
+                       b.perm, d_out, d_stats);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

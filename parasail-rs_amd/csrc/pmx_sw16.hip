@@ -83,6 +83,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                      int msize, int open, int ext, int RP /* rsym stride, bytes */,
                      int q_shared /* > 0: every pair uses qbuf[0..q_shared) */,
                      int limit /* M3 only: biased scores at or above this are flagged for a re-run */,
+                     const unsigned *__restrict__ perm,
                      pmx_record_t *__restrict__ out)
 {
     static_assert(R % 2 == 0, "rows are stored two per dword");
@@ -106,7 +107,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     unsigned char *rsym = lds + NP * PROF_STRIDE + QP * 2;
     int16_t *mat = reinterpret_cast<int16_t *>(rsym + NP * RP);
     unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
-    int *ptab = reinterpret_cast<int *>(map + 256 + ((4 - ((msize * msize * 2) & 3)) & 3));
+    long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));   // per pair: q offset, qlen, r offset, rlen, pair index
 
     const long long pair0 = (long long)blockIdx.x * NP;
 
@@ -114,21 +115,23 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     for (int i = lane; i < msize * msize; i += 64) mat[i] = gmat[i];
     for (int i = lane; i < 256; i += 64) map[i] = gmap[i];
     if (lane < NP) {
-        long long pi = pair0 + lane; if (pi >= n) pi = n - 1;
+        long long pos = pair0 + lane; if (pos >= n) pos = n - 1;
+        const long long pi = perm ? (long long)perm[pos] : pos;
         const long long qb = q_shared ? 0 : qoff[pi], rb = roff[pi];
-        ptab[4 * lane + 0] = (int)(qb - (q_shared ? 0 : qoff[pair0]));      // offsets relative to the block's first pair
-        ptab[4 * lane + 1] = q_shared ? q_shared : (int)(qoff[pi + 1] - qb);
-        ptab[4 * lane + 2] = (int)(rb - roff[pair0]);
-        ptab[4 * lane + 3] = (int)(roff[pi + 1] - rb);
+        ptab[5 * lane + 0] = qb;
+        ptab[5 * lane + 1] = q_shared ? q_shared : (qoff[pi + 1] - qb);
+        ptab[5 * lane + 2] = rb;
+        ptab[5 * lane + 3] = roff[pi + 1] - rb;
+        ptab[5 * lane + 4] = (pair0 + lane < n) ? pi : -1;
     }
     __syncthreads();
-    const uint8_t *qbase = qbuf + (q_shared ? 0 : qoff[pair0]);
-    const uint8_t *rbase = rbuf + roff[pair0];
+    const uint8_t *qbase = qbuf;
+    const uint8_t *rbase = rbuf;
 
     // ---- reference symbols (with G-1 pad symbols on both sides) -------------------------
     int max_rlen = 0;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) max_rlen = max(max_rlen, ptab[4 * p + 3]);
+    for (int p = 0; p < NP; ++p) max_rlen = max(max_rlen, (int)ptab[5 * p + 3]);
     // Global loads are issued in batches of UB independent loads per lane before anything consumes
     // them: the prologue is latency-bound otherwise (one HBM/L2 round trip per loop iteration).
     constexpr int UB = 8;
@@ -139,9 +142,9 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
             const int item = item0 + u * 64 + lane;
             const int p = min(item / RP, NP - 1), j = item - p * RP;
             const int jj = j - (G - 1);
-            ok[u] = item < NP * RP && jj >= 0 && jj < ptab[4 * p + 3];
+            ok[u] = item < NP * RP && jj >= 0 && jj < (int)ptab[5 * p + 3];
             pad[u] = (NP - p) * msize;
-            raw[u] = ok[u] ? rbase[ptab[4 * p + 2] + jj] : (unsigned char)0;
+            raw[u] = ok[u] ? rbase[ptab[5 * p + 2] + jj] : (unsigned char)0;
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -159,8 +162,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         for (int u = 0; u < QB; ++u) {
             const int item = (it0 + u) * 64 + lane;
             const int p = min(item / QP2, NP - 1), rp = item - p * QP2;
-            const int ql = ptab[4 * p + 1];
-            const uint8_t *qp = qbase + ptab[4 * p + 0];
+            const int ql = (int)ptab[5 * p + 1];
+            const uint8_t *qp = qbase + ptab[5 * p + 0];
             v0[u] = item < NP * QP2 && 2 * rp < ql; v1[u] = item < NP * QP2 && 2 * rp + 1 < ql;
             r0[u] = v0[u] ? qp[2 * rp] : (unsigned char)0;
             r1[u] = v1[u] ? qp[2 * rp + 1] : (unsigned char)0;
@@ -332,8 +335,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     if (g == 0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const long long pi = pair0 + 2 * slot + h;
-            if (pi < n) {
+            const long long pi = ptab[5 * (2 * slot + h) + 4];
+            if (pi >= 0) {
                 const unsigned long long key = h ? keyB : keyA;
                 pmx_record_t rec;
                 rec.score = (int)(key >> 32);
@@ -357,7 +360,7 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
     if (NP * m.msize > 255) return 1;                 // per-pair pad symbol must fit a byte
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
     const size_t lds = (size_t)NP * m.msize * QP * 2 + (size_t)QP * 2 + (size_t)NP * RP +
-                       (size_t)m.msize * m.msize * 2 + 256 + 4 + (size_t)NP * 16;
+                       (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
     if (lds > 160 * 1024) return 1;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
@@ -370,7 +373,7 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
     if (blocks <= 0) return 0;
     hipLaunchKernelGGL((pmx_sw16_kernel<G, R, VAR>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
-                       m.msize, open, ext, RP, b.q_shared, M3_LIMIT(m.max), d_out);
+                       m.msize, open, ext, RP, b.q_shared, M3_LIMIT(m.max), b.perm, d_out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

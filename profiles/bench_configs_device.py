@@ -61,4 +61,4 @@ qbuf = np.tile(q, n); qoff = np.arange(n + 1, dtype=np.int64) * 1000
 lens = np.exp(rng.uniform(np.log(500), np.log(5000), size=n)).astype(np.int64)
 roff = np.zeros(n + 1, dtype=np.int64); np.cumsum(lens, out=roff[1:])
 rbuf = DNA[rng.integers(0, 4, size=int(roff[-1]))]
-run("cfg5 sw_striped_sat 1kbp x 0.5-5kbp", pkg.pmx_config_t(pkg.MODE_SW, 0, 5, 2, 0, 0, dna.inner), qbuf, qoff, rbuf, roff, 1000, 5000, reps=3)
+run("cfg5 sw_striped_sat 1kbp x 0.5-5kbp (length-sorted)", pkg.pmx_config_t(pkg.MODE_SW, 0, 5, 2, 0, 4, dna.inner), qbuf, qoff, rbuf, roff, 1000, 5000, reps=3)

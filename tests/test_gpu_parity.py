@@ -505,7 +505,7 @@ def _stats_case(pkg, orc, mode, sg, qs, rs, open_, ext, pm, om, shared_query=Non
 def test_stats16_gap_models(pkg, orc, gaps):
     rng = np.random.default_rng(5000 + gaps[0])
     pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
-    qs = random_seqs(rng, 150, 1, 160)
+    qs = random_seqs(rng, 300, 1, 160)          # ragged and >= 256 pairs: also exercises the length-sorted order
     rs = [mutate(rng, q, 0.12, 0.06) if i % 4 else random_seqs(rng, 1, 1, 300)[0] for i, q in enumerate(qs)]
     for mode in (0, 1):
         _stats_case(pkg, orc, mode, None, qs, rs, gaps[0], gaps[1], pm, om)
