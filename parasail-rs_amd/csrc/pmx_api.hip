@@ -410,6 +410,27 @@ struct RunSpec {
     int vecflag;           // F_STRIPED / F_SCAN / F_DIAG / 0
 };
 
+static int run_batch_device(const pmx_config_t *cfg, int64_t n,
+                            const uint8_t *d_qbuf, const int64_t *d_qoff, int q_shared,
+                            const uint8_t *d_rbuf, const int64_t *d_roff,
+                            int32_t max_qlen, int32_t max_rlen,
+                            pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream);
+
+// One device block + one pinned host block per thread for the one-pair entry: a single H2D, the
+// kernel(s), a single D2H.  (The reference's call is a CPU function of ~20 us; no allocation per call.)
+struct SingleWs { void *dev = nullptr; void *pin = nullptr; size_t cap = 0; int device = -1; };
+static thread_local SingleWs g_single;
+static void single_reserve(size_t bytes)
+{
+    int dev = 0; HIP_OR_DIE(hipGetDevice(&dev));
+    if (g_single.device == dev && g_single.cap >= bytes) return;
+    if (g_single.dev) { (void)hipFree(g_single.dev); (void)hipHostFree(g_single.pin); }
+    const size_t cap = bytes < 65536 ? 65536 : bytes * 2;
+    HIP_OR_DIE(hipMalloc(&g_single.dev, cap));
+    HIP_OR_DIE(hipHostMalloc(&g_single.pin, cap, hipHostMallocDefault));
+    g_single.cap = cap; g_single.device = dev;
+}
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -437,6 +458,35 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
     if (get_devmat(matrix, &dm)) die(g_err, hipSuccess);
     const bool pssm = matrix->type == PARASAIL_MATRIX_TYPE_PSSM;
     if (pssm && matrix->length != s1Len) die("PSSM length differs from the query length", hipSuccess);
+
+    if (!sp.table && !sp.rowcol && !sp.trace && sp.band < 0 && !pssm) {
+        // score (+ stats) only: a one-pair batch through the same dispatcher as pmx_align_batch_device
+        const size_t qpad = ((size_t)s1Len + 7) & ~(size_t)7, rpad = ((size_t)s2Len + 7) & ~(size_t)7;
+        const size_t in_bytes = qpad + rpad + 4 * sizeof(int64_t);
+        const size_t total = in_bytes + 64;
+        single_reserve(total);
+        unsigned char *h = (unsigned char *)g_single.pin, *d = (unsigned char *)g_single.dev;
+        memcpy(h, s1, (size_t)s1Len); memcpy(h + qpad, s2, (size_t)s2Len);
+        const int64_t offs[4] = {0, s1Len, 0, s2Len};
+        memcpy(h + qpad + rpad, offs, sizeof offs);
+        HIP_OR_DIE(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, nullptr));
+        pmx_config_t cfg; memset(&cfg, 0, sizeof cfg);
+        cfg.mode = sp.mode; cfg.sg_flags = sp.sg_flags; cfg.open = open; cfg.extend = gap; cfg.width = sp.width;
+        cfg.want = sp.stats ? PMX_WANT_STATS : 0; cfg.matrix = matrix;
+        pmx_record_t *drec = (pmx_record_t *)(d + in_bytes);
+        pmx_stats_t *dst = (pmx_stats_t *)(d + in_bytes + 16);
+        const int64_t *doff = (const int64_t *)(d + qpad + rpad);
+        if (run_batch_device(&cfg, 1, d, doff, 0, d + qpad, doff + 2, s1Len, s2Len, drec, sp.stats ? dst : nullptr, nullptr))
+            die(g_err, hipSuccess);
+        HIP_OR_DIE(hipMemcpyAsync(h + in_bytes, d + in_bytes, 32, hipMemcpyDeviceToHost, nullptr));
+        HIP_OR_DIE(hipStreamSynchronize(nullptr));
+        pmx_record_t rec; pmx_stats_t st;
+        memcpy(&rec, h + in_bytes, sizeof rec); memcpy(&st, h + in_bytes + 16, sizeof st);
+        res->score = rec.score; res->end_query = rec.end_query; res->end_ref = rec.end_ref;
+        if (rec.flags & PMX_FLAG_SATURATED) res->flag |= F_SATURATED;
+        if (sp.stats) { res->matches = st.matches; res->similar = st.similar; res->length = st.length; }
+        return res;
+    }
 
     const size_t cells = (size_t)s1Len * s2Len;
     DevBuf<uint8_t> dq, dr; DevBuf<int64_t> doff; DevBuf<pmx_record_t> drec; DevBuf<pmx_stats_t> dst;
