@@ -274,6 +274,11 @@ int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_profile_t *p
                             const uint8_t *rbuf, const int64_t *roff,
                             pmx_record_t *out, pmx_stats_t *stats_out);
 
+/* The same with device-resident references (device pointers, asynchronous on `stream`). */
+int pmx_align_profile_batch_device(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,
+                                   const uint8_t *d_rbuf, const int64_t *d_roff, int32_t max_rlen,
+                                   pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream);
+
 /* CIGAR text for a batch (semi-global / global / local with traceback done on the device).
  * cigar_off has n+1 entries; *cigar_buf is malloc'd by the callee and freed with pmx_free. */
 int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,

@@ -59,7 +59,7 @@ STATS_DTYPE = np.dtype([("matches", "<i4"), ("similar", "<i4"), ("length", "<i4"
 
 MODE_NW, MODE_SG, MODE_SW = 0, 1, 2
 SG_QB, SG_QE, SG_DB, SG_DE, SG_ALL = 1, 2, 4, 8, 15
-WANT_STATS, WANT_CIGAR = 1, 2
+WANT_STATS, WANT_CIGAR, WANT_SORTED = 1, 2, 4
 FLAG_SATURATED = 1
 
 _MP = C.POINTER(parasail_matrix_t)
@@ -119,6 +119,8 @@ _sig("pmx_align_batch_device", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_
      C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("pmx_align_profile_batch", C.c_int, C.POINTER(pmx_config_t), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
      C.c_void_p, C.c_void_p)
+_sig("pmx_align_profile_batch_device", C.c_int, C.POINTER(pmx_config_t), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("pmx_align_batch_cigar", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
      C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p)
 _libc_free = C.CDLL(None).free
@@ -775,6 +777,13 @@ def align_batch_device(cfg, n, d_qbuf, d_qoff, d_rbuf, d_roff, max_qlen, max_rle
     """Device-pointer entry (ints are raw device addresses, `stream` a hipStream_t value)."""
     rc = lib.pmx_align_batch_device(C.byref(cfg), n, d_qbuf, d_qoff, d_rbuf, d_roff, max_qlen, max_rlen,
                                     d_out, d_stats, stream)
+    if rc:
+        raise BatchError(lib.pmx_last_error().decode())
+
+
+def align_profile_batch_device(cfg, profile, n, d_rbuf, d_roff, max_rlen, d_out, d_stats=None, stream=0):
+    """One reused query profile against device-resident references."""
+    rc = lib.pmx_align_profile_batch_device(C.byref(cfg), profile.inner, n, d_rbuf, d_roff, max_rlen, d_out, d_stats, stream)
     if rc:
         raise BatchError(lib.pmx_last_error().decode())
 

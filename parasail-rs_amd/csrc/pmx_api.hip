@@ -624,6 +624,8 @@ struct parasail_profile {
     char *s1; int s1Len;
     const parasail_matrix_t *matrix;
     int stats; int width;
+    // device copy of the query for the batch entries (uploaded on first use, per device)
+    mutable uint8_t *d_s1; mutable int d_dev; mutable std::mutex *mx;
 };
 
 static parasail_profile_t *profile_new(const char *s1, int s1Len, const parasail_matrix_t *matrix, int stats, int width)
@@ -635,9 +637,30 @@ static parasail_profile_t *profile_new(const char *s1, int s1Len, const parasail
     if (!p->s1) { free(p); return nullptr; }
     memcpy(p->s1, s1, (size_t)s1Len); p->s1[s1Len] = 0;
     p->s1Len = s1Len; p->matrix = matrix; p->stats = stats; p->width = width;
+    p->d_s1 = nullptr; p->d_dev = -1; p->mx = new std::mutex;
     return p;
 }
-extern "C" void parasail_profile_free(parasail_profile_t *p) { if (p) { free(p->s1); free(p); } }
+extern "C" void parasail_profile_free(parasail_profile_t *p)
+{
+    if (!p) return;
+    if (p->d_s1) (void)hipFree(p->d_s1);
+    delete p->mx;
+    free(p->s1); free(p);
+}
+static int profile_device_query(const parasail_profile_t *p, const uint8_t **out)
+{
+    int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(*p->mx);
+    if (!p->d_s1 || p->d_dev != dev) {
+        if (p->d_s1) (void)hipFree(p->d_s1);
+        p->d_s1 = nullptr;
+        HIP_OR_RET(hipMalloc(&p->d_s1, (size_t)p->s1Len));
+        HIP_OR_RET(hipMemcpy(p->d_s1, p->s1, (size_t)p->s1Len, hipMemcpyHostToDevice));
+        p->d_dev = dev;
+    }
+    *out = p->d_s1;
+    return 0;
+}
 
 #define PMX_DEFINE_PROFILE_CREATORS(ISA)                                                                    \
     extern "C" parasail_profile_t *parasail_profile_create##ISA##_sat(const char *s, const int n, const parasail_matrix_t *m) { return profile_new(s, n, m, 0, 0); }  \
@@ -1109,9 +1132,10 @@ extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_p
     DevMat dm;
     if (get_devmat(cfg->matrix, &dm)) return -1;
     const size_t rbytes = (size_t)roff[n];
-    DevBuf<uint8_t> dq, dr; DevBuf<int64_t> dro; DevBuf<pmx_record_t> drec; DevBuf<pmx_stats_t> dst;
-    dq.alloc(profile->s1Len); dr.alloc(rbytes); dro.alloc(n + 1); drec.alloc(n); if (stats) dst.alloc(n);
-    HIP_OR_RET(hipMemcpy(dq.p, profile->s1, profile->s1Len, hipMemcpyHostToDevice));
+    DevBuf<uint8_t> dr; DevBuf<int64_t> dro; DevBuf<pmx_record_t> drec; DevBuf<pmx_stats_t> dst;
+    struct { const uint8_t *p; } dq;
+    if (profile_device_query(profile, &dq.p)) return -1;
+    dr.alloc(rbytes); dro.alloc(n + 1); drec.alloc(n); if (stats) dst.alloc(n);
     HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     const int rc = run_batch_device(cfg, n, dq.p, nullptr, profile->s1Len, dr.p, dro.p, profile->s1Len, mr,
@@ -1120,6 +1144,21 @@ extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_p
     HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
     if (stats) HIP_OR_RET(hipMemcpy(stats_out, dst.p, sizeof(pmx_stats_t) * n, hipMemcpyDeviceToHost));
     return 0;
+}
+
+// Device-resident references against one reused query profile, asynchronous on `stream`.
+extern "C" int pmx_align_profile_batch_device(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,
+                                              const uint8_t *d_rbuf, const int64_t *d_roff, int32_t max_rlen,
+                                              pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream)
+{
+    if (check_cfg(cfg)) return -1;
+    if (!profile) { set_err("null profile"); return -1; }
+    if (profile->matrix != cfg->matrix) { set_err("profile was built with a different matrix"); return -1; }
+    if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
+    const uint8_t *dq = nullptr;
+    if (profile_device_query(profile, &dq)) return -1;
+    return run_batch_device(cfg, n, dq, nullptr, profile->s1Len, d_rbuf, d_roff, profile->s1Len, max_rlen,
+                            d_out, d_stats_out, stream);
 }
 
 // CIGAR for a batch.  Fast path: pmx_trace16 (4-bit trace in HBM, on-device walk); otherwise the general

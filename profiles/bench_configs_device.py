@@ -46,6 +46,21 @@ q = AA[rng.integers(0, 20, size=300)]
 qbuf = np.tile(q, n); qoff = np.arange(n + 1, dtype=np.int64) * 300
 rbuf, roff = randbatch(n, 4500, 5000, AA)
 run("cfg3 nw_stats_striped_16 300aa x ~4.75kaa", pkg.pmx_config_t(pkg.MODE_NW, 0, 11, 1, 16, pkg.WANT_STATS, b62.inner), qbuf, qoff, rbuf, roff, 300, 5000, stats=True, reps=3)
+# the same through the profile arm: one shared query profile per 4-wave workgroup
+prof = pkg.Profile.new(q.tobytes(), True, b62)
+cfgp = pkg.pmx_config_t(pkg.MODE_NW, 0, 11, 1, 16, pkg.WANT_STATS, b62.inner)
+d_r = torch.from_numpy(rbuf).to(dev); d_ro = torch.from_numpy(roff).to(dev)
+outp = torch.zeros((n, 4), dtype=torch.int32, device=dev); stp = torch.zeros((n, 3), dtype=torch.int32, device=dev)
+stream = torch.cuda.current_stream(dev)
+def oncep():
+    pkg.align_profile_batch_device(cfgp, prof, n, d_r.data_ptr(), d_ro.data_ptr(), 5000, outp.data_ptr(), stp.data_ptr(), stream.cuda_stream)
+oncep(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(stream)
+for _ in range(3): oncep()
+e1.record(stream); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 3
+print("%-44s n=%-7d %8.1f GCUPS  (%.3f ms)" % ("cfg3 nw_stats_striped_profile_16 (shared profile)", n, 300 * int((roff[1:] - roff[:-1]).sum()) / ms / 1e6, ms))
 run("cfg3b nw_striped_16 (score only)", pkg.pmx_config_t(pkg.MODE_NW, 0, 11, 1, 16, 0, b62.inner), qbuf, qoff, rbuf, roff, 300, 5000, reps=3)
 # cfg4b sg score-only 250x250
 n = 1000000
