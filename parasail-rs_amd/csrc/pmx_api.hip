@@ -1267,10 +1267,12 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
     std::string text;
     cigar_off[0] = 0;
     // chunks keep the per-launch trace scratch below ~16 GiB (a pair needs at most ~(qlen+64)*(rlen+64)/2 bytes)
+    double chunk_bytes = 16e9;
+    if (const char *e = getenv("PMX_CIGAR_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
     int64_t c0 = 0;
     while (c0 < n) {
         int64_t c1 = c0; double bytes = 0;
-        while (c1 < n && (c1 == c0 || bytes < 16e9)) {
+        while (c1 < n && (c1 == c0 || bytes < chunk_bytes)) {
             bytes += 1.0 * (double)(qoff[c1 + 1] - qoff[c1] + 64) * (double)(roff[c1 + 1] - roff[c1] + 64);
             ++c1;
         }

@@ -580,6 +580,18 @@ def test_trace16_cigar_sg_variants_and_sizes(pkg, orc):
         _cigar_case(pkg, orc, 0, None, q2, r2, 5, 2, pm, om)
 
 
+def test_batch_cigar_chunking(pkg, orc, monkeypatch):
+    """the batch CIGAR entry processes chunks that bound the trace scratch: force several chunks"""
+    rng = np.random.default_rng(4150)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 70, 50, 200)
+    rs = [mutate(rng, q, 0.1, 0.04) for q in qs]
+    monkeypatch.setenv("PMX_CIGAR_CHUNK_BYTES", "300000")        # ~5-10 pairs per chunk
+    _cigar_case(pkg, orc, 1, None, qs, rs, 5, 2, pm, om)
+    monkeypatch.setenv("PMX_CIGAR_CHUNK_BYTES", "1")             # one pair per chunk
+    _cigar_case(pkg, orc, 0, None, qs[:9], rs[:9], 5, 2, pm, om)
+
+
 def test_trace16_cigar_blosum62(pkg, orc):
     rng = np.random.default_rng(4200)
     pm = pkg.Matrix.from_name("blosum62")
