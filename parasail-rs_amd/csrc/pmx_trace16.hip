@@ -55,7 +55,7 @@ __device__ __forceinline__ unsigned t_shift_up(unsigned x, unsigned neutral, int
     }
 }
 
-template <int G, int R>
+template <int G, int R, bool SW>
 __global__ __launch_bounds__(64)
 void pmx_trace16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                         const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
@@ -170,6 +170,10 @@ void pmx_trace16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     unsigned diag0 = (g == 0) ? (unsigned)TB : left_h(g * R - 1);
 
     int res = TB, bestrow = 0, bestrowj = 0, bestcol = 0, bestcoli = 0;
+    // local alignment: running best of this lane, the column where it was first exceeded, the strip at that column
+    unsigned swbest = (unsigned)TB, swcol = 0u, swsave[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) swsave[k] = (unsigned)TB;
     uint32_t *tw = tbuf + ((size_t)blockIdx.x * Tmax) * (64 * TW) + lane * TW;
 
     auto load_scores = [&](int sym, unsigned (&w)[R]) {
@@ -187,7 +191,8 @@ void pmx_trace16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         for (int k = 0; k < R; ++k) {
             const unsigned d = (k == 0) ? diag0 : Hold[k - 1];
             const unsigned Tt = a16(d, w[k]);
-            const unsigned H = m16(m16(Tt, E[k]), F);
+            unsigned H = m16(m16(Tt, E[k]), F);
+            if (SW) H = m16(H, (unsigned)TB);          // local: floor at zero (the walk stops where the score is used up)
             push_lt(plane[k / 8], Tt, H);          // ND
             push_lt(plane[k / 8], F, H);           // NDL
             const unsigned Ho = s16(H, vOpen);
@@ -206,6 +211,17 @@ void pmx_trace16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 
         // ---- captures ----
         const int jcol = t - g;
+        if (SW) {
+            unsigned cm = Hnew[0] & 0xFFFFu;
+#pragma unroll
+            for (int k = 1; k < R; ++k) cm = m16(cm, Hnew[k]) & 0xFFFFu;
+            const bool imp = cm > swbest;          // strictly greater: the first column reaching a value keeps it
+            swbest = imp ? cm : swbest;
+            swcol = imp ? (unsigned)jcol : swcol;
+#pragma unroll
+            for (int k = 0; k < R; ++k) swsave[k] = imp ? Hnew[k] : swsave[k];
+            return;
+        }
         const int hl = (int)(Hout & 0xFFFF);
         if (jcol == rl - 1) res = hl;
         if (s2_end && jcol >= 0 && jcol < rl && hl > bestrow) { bestrow = hl; bestrowj = jcol; }
@@ -238,6 +254,30 @@ void pmx_trace16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (SW) {
+        int krow = 0;
+#pragma unroll
+        for (int k = R - 1; k >= 0; --k) if ((swsave[k] & 0xFFFFu) == swbest) krow = k;
+        unsigned long long key = ((unsigned long long)swbest << 32) | ((unsigned long long)(0xFFFFu - (swcol & 0xFFFFu)) << 16) |
+                                 (unsigned long long)(0xFFFFu - (unsigned)(g * R + krow));
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off, 64);
+            key = o > key ? o : key;
+        }
+        if (g == 0) {
+            const long long pi = pair0 + slot;
+            if (pi < n) {
+                pmx_record_t rec; rec.flags = 0;
+                rec.score = (int)(key >> 32) - TB;
+                rec.end_ref = 0xFFFF - (int)((key >> 16) & 0xFFFF);
+                rec.end_query = 0xFFFF - (int)(key & 0xFFFF) - P;
+                if (rec.score == 0) { rec.end_query = 0; rec.end_ref = 0; }      // all-zero table: (0, 0) like the oracle
+                out[pi] = rec;
+            }
+        }
+        return;
+    }
     // ---- combine (same rules as pmx_nwsg16.hip / the oracle) ---------------------------------
     unsigned key = ((unsigned)bestcol << 16) | (0xFFFFu - (unsigned)bestcoli);
 #pragma unroll
@@ -269,7 +309,8 @@ void pmx_trace16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 // ---- walk over the 4-bit trace ---------------------------------------------------------------
 template <int G, int R>
 __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
-                                  long long n, const uint8_t *mapper, int mode, int Tmax,
+                                  long long n, const uint8_t *mapper, const int16_t *scores, int msize, int open, int ext,
+                                  int mode, int Tmax,
                                   const uint32_t *tbuf, const pmx_record_t *recs,
                                   uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg)
 {
@@ -300,21 +341,29 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
         else if (j + 1 == rl) { for (int k = ql - 1; k > i; --k) emit(OP_FOR_DEL_STATE); }
     }
     int where = 0;   // 0 DIAG, 1 INS, 2 DEL
+    const bool sw = mode == PMX_MODE_SW;
+    int rem = rec.score;       // local alignment: value of the current H / E / F cell; the path starts where it is used up
     while (i >= 0 || j >= 0) {
-        if (i < 0) { emit(OP_FOR_INS_STATE); --j; continue; }
-        if (j < 0) { emit(OP_FOR_DEL_STATE); --i; continue; }
+        if (i < 0) { if (sw) break; emit(OP_FOR_INS_STATE); --j; continue; }
+        if (j < 0) { if (sw) break; emit(OP_FOR_DEL_STATE); --i; continue; }
         if (where == 0) {
+            if (sw && rem <= 0) break;                       // ZERO cell
             const unsigned t = nib(i, j);
-            if (!(t & 8u)) { emit(mapper[q[i]] == mapper[r[j]] ? OP_EQ : OP_X); --i; --j; }
+            if (!(t & 8u)) {
+                const int a = mapper[q[i]], b = mapper[r[j]];
+                emit(a == b ? OP_EQ : OP_X);
+                rem -= scores[a * msize + b];
+                --i; --j;
+            }
             else if (!(t & 4u)) where = 2;
             else where = 1;
         } else if (where == 1) {
             emit(OP_FOR_INS_STATE);
-            if (j > 0 && (nib(i, j - 1) & 2u)) where = 0;
+            if (j > 0 && (nib(i, j - 1) & 2u)) { where = 0; rem += open; } else rem += ext;
             --j;
         } else {
             emit(OP_FOR_DEL_STATE);
-            if (nib(i - 1, j) & 1u) where = 0;
+            if (nib(i - 1, j) & 1u) { where = 0; rem += open; } else rem += ext;
             --i;
         }
     }
@@ -325,7 +374,7 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
 }
 
 // ------------------------------------------------------------------------ host side ----
-template <int G, int R>
+template <int G, int R, bool SW>
 static int launch_trace(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                         pmx_record_t *d_out, uint32_t *tbuf, int Tmax,
                         uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream)
@@ -337,22 +386,22 @@ static int launch_trace(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     if (lds > 160 * 1024) return 1;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_trace16_kernel<G, R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_trace16_kernel<G, R, SW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
     const bool sg = mode == PMX_MODE_SG;
-    const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
+    const int col_pen = SW ? 0 : !(sg && (sg_flags & PMX_SG_QB)), row_pen = SW ? 0 : !(sg && (sg_flags & PMX_SG_DB));
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
     const long long blocks = (b.n + NP - 1) / NP;
-    hipLaunchKernelGGL((pmx_trace16_kernel<G, R>), dim3((unsigned)blocks), dim3(64), lds, stream,
+    hipLaunchKernelGGL((pmx_trace16_kernel<G, R, SW>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                        m.msize, open, ext, RP, Tmax, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, d_out, tbuf);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e;
     hipLaunchKernelGGL((pmx_walk16_kernel<G, R>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream,
-                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, mode, Tmax,
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax,
                        (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
@@ -364,11 +413,12 @@ int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int ope
                      int *variant, int *Tmax, size_t *trace_bytes)
 {
     if (getenv("PMX_NO_FAST_TRACE")) return 1;
-    if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
+    if (mode != PMX_MODE_NW && mode != PMX_MODE_SG && mode != PMX_MODE_SW) return 1;
     if (m.msize > PMX_MAX_FAST_MSIZE - 1) return 1;
     if (open < ext || open < 0 || ext < 0 || open > 4096) return 1;
     if (b.max_rlen > 30000 || b.q_shared) return 1;
-    const long long lo = -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
+    const long long lo = mode == PMX_MODE_SW ? -(2LL * open + 2LL * ext + (m.min < 0 ? -m.min : 0))
+                                             : -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
     const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);
     if (lo < -15000 || hi > 15000) return 1;
     int G, R;
@@ -387,10 +437,14 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
                        pmx_record_t *d_out, uint32_t *tbuf, int Tmax,
                        uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream)
 {
+    const bool sw = mode == PMX_MODE_SW;
+#define LT(GG, RR) (sw ? launch_trace<GG, RR, true>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stream) \
+                       : launch_trace<GG, RR, false>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stream))
     switch (variant) {
-    case 0: return launch_trace<32, 8>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stream);
-    case 1: return launch_trace<64, 8>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stream);
-    case 2: return launch_trace<64, 16>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stream);
+    case 0: return LT(32, 8);
+    case 1: return LT(64, 8);
+    case 2: return LT(64, 16);
     }
+#undef LT
     return 1;
 }

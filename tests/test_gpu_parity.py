@@ -580,6 +580,21 @@ def test_trace16_cigar_sg_variants_and_sizes(pkg, orc):
         _cigar_case(pkg, orc, 0, None, q2, r2, 5, 2, pm, om)
 
 
+@pytest.mark.parametrize("gaps", [(5, 2), (0, 0), (1, 1), (11, 1), (3, 0)])
+def test_trace16_cigar_local(pkg, orc, gaps):
+    """sw_trace through the fast traceback kernel: zero floor in the DP, the walk stops where the score is used up"""
+    rng = np.random.default_rng(4300 + gaps[0])
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 150, 1, 250)
+    rs = [random_seqs(rng, 1, 0, 40)[0] + mutate(rng, q, 0.12, 0.06) + random_seqs(rng, 1, 0, 40)[0] if i % 4
+          else random_seqs(rng, 1, 1, 300)[0] for i, q in enumerate(qs)]
+    qs += [b"A", b"ACGT"]; rs += [b"C", b"TTTT"]                  # all-zero tables
+    _cigar_case(pkg, orc, 2, None, qs, rs, gaps[0], gaps[1], pm, om)
+    q2 = random_seqs(rng, 10, 300, 1000)
+    r2 = [mutate(rng, q, 0.1, 0.03) for q in q2]
+    _cigar_case(pkg, orc, 2, None, q2, r2, gaps[0], gaps[1], pm, om)
+
+
 def test_batch_cigar_chunking(pkg, orc, monkeypatch):
     """the batch CIGAR entry processes chunks that bound the trace scratch: force several chunks"""
     rng = np.random.default_rng(4150)
