@@ -1025,8 +1025,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         }
         // rc == 1: shape not covered by the fast kernel -> general kernel below
     }
-    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && want == PMX_WANT_STATS && cfg->width != 8 &&
-        cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
+    if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
         const int rc = pmx_launch_stats16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, d_stats_out, st, nullptr);
         if (rc < 0) { set_err("stats16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
         if (rc == 0) return 0;

@@ -43,7 +43,7 @@ __device__ __forceinline__ unsigned s_shift_up(unsigned x)
 
 struct SCand { int H, i, j; unsigned MS, L; };
 
-template <int G, int R, int WAVES>
+template <int G, int R, int WAVES, bool SW>
 __global__ __launch_bounds__(64 * WAVES)
 void pmx_stats16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                         const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
@@ -152,6 +152,10 @@ void pmx_stats16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     unsigned diagMS0 = 0u, diagL0 = (g == 0) ? 0u : (col_pen ? (unsigned)(g * R) : 0u);
 
     SCand corner = {-(1 << 30), 0, 0, 0u, 0u}, brow = corner, bcol = corner;
+    // local: running best of the lane, first column that reached it, H / stats strips at that column
+    unsigned swbest = (unsigned)SB, swcol = 0u, svH[R], svMS[R], svL[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { svH[k] = (unsigned)SB; svMS[k] = 0u; svL[k] = 0u; }
 
     auto load_scores = [&](int sym, unsigned (&w)[R], unsigned (&wi)[R]) {
 #pragma unroll
@@ -177,10 +181,16 @@ void pmx_stats16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             const unsigned dL = (k == 0) ? diagL0 : Lold[k - 1];
             const unsigned Tt = sa16(d, w[k]);
             const unsigned TMS = dMS + wi[k], TL = dL + linc;
-            const unsigned H = sm16(sm16(Tt, E[k]), F);
+            unsigned H = sm16(sm16(Tt, E[k]), F);
             unsigned xMS, xL, hMS, hL;
             sel2_lt(xMS, xL, F, H, EMS[k], EL[k], FMS, FL);        // not from F -> E's stats, else F's
             sel2_lt(hMS, hL, Tt, H, xMS, xL, TMS, TL);             // not diagonal -> gap stats, else diagonal's
+            if (SW) {                                              // local: H <= 0 restarts the alignment
+                unsigned zMS, zL;
+                sel2_lt(zMS, zL, (unsigned)SB, H, hMS, hL, 0u, 0u);
+                hMS = zMS; hL = zL;
+                H = sm16(H, (unsigned)SB);
+            }
             const unsigned Ho = ss16(H, vOpen), Ee = ss16(E[k], vExt), Fe = ss16(F, vExt);
             unsigned eMS, eL, fMS, fL;
             sel2_lt(eMS, eL, Ee, Ho, hMS, hL, EMS[k], EL[k]);      // E opened from H
@@ -196,6 +206,17 @@ void pmx_stats16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         Fout = F; FMSout = FMS; FLout = FL;
 
         // ---- captures ----
+        if (SW) {
+            unsigned cm = Hnew[0] & 0xFFFFu;
+#pragma unroll
+            for (int k = 1; k < R; ++k) cm = sm16(cm, Hnew[k]) & 0xFFFFu;
+            const bool imp = cm > swbest;
+            swbest = imp ? cm : swbest;
+            swcol = imp ? (unsigned)jcol : swcol;
+#pragma unroll
+            for (int k = 0; k < R; ++k) { svH[k] = imp ? Hnew[k] : svH[k]; svMS[k] = imp ? MSnew[k] : svMS[k]; svL[k] = imp ? Lnew[k] : svL[k]; }
+            return;
+        }
         if (jcol >= 0 && jcol < rl) {
             if (g == gL && (s2_end || jcol == rl - 1)) {
                 unsigned h = 0, ms = 0, l = 0;
@@ -235,6 +256,36 @@ void pmx_stats16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (SW) {
+        int krow = 0; unsigned kMS = svMS[0], kL = svL[0];
+#pragma unroll
+        for (int k = R - 1; k >= 0; --k) if ((svH[k] & 0xFFFFu) == swbest) { krow = k; kMS = svMS[k]; kL = svL[k]; }
+        const unsigned long long mykey = ((unsigned long long)swbest << 32) | ((unsigned long long)(0xFFFFu - (swcol & 0xFFFFu)) << 16) |
+                                         (unsigned long long)(0xFFFFu - (unsigned)(g * R + krow));
+        unsigned long long key = mykey;
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off, 64);
+            key = o > key ? o : key;
+        }
+        const unsigned long long win = __ballot(key == mykey);
+        const unsigned long long slotmask = (G == 64) ? ~0ULL : (((1ULL << G) - 1ULL) << ((lane / G) * G));
+        const int wl = __builtin_ctzll(win & slotmask);
+        const unsigned wMS = __shfl(kMS, wl, 64), wL = __shfl(kL, wl, 64);
+        if (g == 0) {
+            const long long pi = ptab[5 * slot + 4];
+            if (pi >= 0) {
+                pmx_record_t rec; rec.flags = 0;
+                rec.score = (int)(key >> 32) - SB;
+                rec.end_ref = 0xFFFF - (int)((key >> 16) & 0xFFFF);
+                rec.end_query = 0xFFFF - (int)(key & 0xFFFF);
+                pmx_stats_t st; st.matches = (int)(wMS & 0xFFFF); st.similar = (int)(wMS >> 16); st.length = (int)wL;
+                if (rec.score == 0) { rec.end_query = 0; rec.end_ref = 0; st.matches = st.similar = st.length = 0; }
+                out[pi] = rec; stats_out[pi] = st;
+            }
+        }
+        return;
+    }
     // ---- combine: last-column candidates over the slot (value desc, row asc), then the oracle's rule ----
     unsigned key = ((unsigned)(bcol.H < 0 ? 0 : bcol.H) << 16) | (0xFFFFu - (unsigned)bcol.i);
     unsigned best = key;
@@ -275,7 +326,7 @@ void pmx_stats16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 }
 
 // ------------------------------------------------------------------------ host side ----
-template <int G, int R, int WAVES>
+template <int G, int R, int WAVES, bool SW>
 static int launch_stats(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                         pmx_record_t *d_out, pmx_stats_t *d_stats, hipStream_t stream)
 {
@@ -287,16 +338,16 @@ static int launch_stats(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     if (lds > 160 * 1024) return 1;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_stats16_kernel<G, R, WAVES>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_stats16_kernel<G, R, WAVES, SW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e;
         attr_done = true;
     }
     const bool sg = mode == PMX_MODE_SG;
-    const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
+    const int col_pen = SW ? 0 : !(sg && (sg_flags & PMX_SG_QB)), row_pen = SW ? 0 : !(sg && (sg_flags & PMX_SG_DB));
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
     const long long blocks = (b.n + NP - 1) / NP;
-    hipLaunchKernelGGL((pmx_stats16_kernel<G, R, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream,
+    hipLaunchKernelGGL((pmx_stats16_kernel<G, R, WAVES, SW>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                        m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0,
                        b.perm, d_out, d_stats);
@@ -309,19 +360,23 @@ int pmx_launch_stats16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
                        pmx_record_t *d_out, pmx_stats_t *d_stats, hipStream_t stream, const char **kernel_name)
 {
     if (getenv("PMX_NO_FAST_STATS")) return 1;
-    if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
+    if (mode != PMX_MODE_NW && mode != PMX_MODE_SG && mode != PMX_MODE_SW) return 1;
     if (m.msize > PMX_MAX_FAST_MSIZE - 1) return 1;
     if (ext < 1 || open < ext || open > 4096) return 1;
     if (b.max_rlen > 30000 || b.max_qlen + b.max_rlen > 60000) return 1;
-    const long long lo = -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
+    const long long lo = mode == PMX_MODE_SW ? -(2LL * open + 2LL * ext + (m.min < 0 ? -m.min : 0))
+                                             : -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
     const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);
     if (lo < -15000 || hi > 15000) return 1;
     const int q = b.max_qlen;
     const int W = b.q_shared ? 4 : 1;      // a shared query profile is built once per 4-wave workgroup
 #define TRYS(GG, RR, NAME)                                                      \
     if (q <= (GG) * (RR)) {                                                     \
-        int rc = W == 4 ? launch_stats<GG, RR, 4>(b, m, mode, sg_flags, open, ext, d_out, d_stats, stream) \
-                        : launch_stats<GG, RR, 1>(b, m, mode, sg_flags, open, ext, d_out, d_stats, stream); \
+        int rc = mode == PMX_MODE_SW                                                                        \
+            ? (W == 4 ? launch_stats<GG, RR, 4, true>(b, m, mode, sg_flags, open, ext, d_out, d_stats, stream)  \
+                      : launch_stats<GG, RR, 1, true>(b, m, mode, sg_flags, open, ext, d_out, d_stats, stream)) \
+            : (W == 4 ? launch_stats<GG, RR, 4, false>(b, m, mode, sg_flags, open, ext, d_out, d_stats, stream) \
+                      : launch_stats<GG, RR, 1, false>(b, m, mode, sg_flags, open, ext, d_out, d_stats, stream)); \
         if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; }       \
     }
     TRYS(16, 10, "pmx_stats16_kernel<16,10>")

@@ -483,7 +483,7 @@ def test_batch_cigar_semi_global(pkg, orc):
 
 def _stats_case(pkg, orc, mode, sg, qs, rs, open_, ext, pm, om, shared_query=None):
     b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext).solution_width(16)
-    [b.global_, b.semi_global][mode]()
+    [b.global_, b.semi_global, b.local][mode]()
     if mode == 1 and sg is not None:
         qg = [n for f, n in ((orc.S1_BEG, "prefix"), (orc.S1_END, "suffix")) if sg & f]
         dg = [n for f, n in ((orc.S2_BEG, "prefix"), (orc.S2_END, "suffix")) if sg & f]
@@ -509,6 +509,21 @@ def test_stats16_gap_models(pkg, orc, gaps):
     rs = [mutate(rng, q, 0.12, 0.06) if i % 4 else random_seqs(rng, 1, 1, 300)[0] for i, q in enumerate(qs)]
     for mode in (0, 1):
         _stats_case(pkg, orc, mode, None, qs, rs, gaps[0], gaps[1], pm, om)
+
+
+@pytest.mark.parametrize("gaps", [(5, 2), (1, 1), (11, 1)])
+def test_stats16_local(pkg, orc, gaps):
+    rng = np.random.default_rng(5050 + gaps[0])
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 300, 1, 160)
+    rs = [random_seqs(rng, 1, 0, 40)[0] + mutate(rng, q, 0.12, 0.06) + random_seqs(rng, 1, 0, 40)[0] if i % 4
+          else random_seqs(rng, 1, 1, 300)[0] for i, q in enumerate(qs)]
+    qs += [b"A", b"ACGT"]; rs += [b"C", b"TTTT"]
+    _stats_case(pkg, orc, 2, None, qs, rs, gaps[0], gaps[1], pm, om)
+    b62, ob62 = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    q = random_seqs(rng, 1, 300, 300, AA)[0]
+    rs2 = [random_seqs(rng, 1, 0, 100, AA)[0] + mutate(rng, q, 0.4, 0.05, AA)[50:250] + random_seqs(rng, 1, 0, 300, AA)[0] for _ in range(40)]
+    _stats_case(pkg, orc, 2, None, None, rs2, 11, 1, b62, ob62, shared_query=q)
 
 
 def test_stats16_sg_variants_and_sizes(pkg, orc):
