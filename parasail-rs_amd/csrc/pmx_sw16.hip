@@ -229,6 +229,17 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         v2s F = PK(group_shift_up<G>(Fout, ZERO2, g));        // F(i0, j)
         v2s colmax = vZero;
         v2s Hcur[R];                                           // V2 only: this column's H (the strips hold H - open)
+        v2s Tpre[R], Epre[R];                                  // V2 only: hoisted independent adds / subtracts
+        if (V2) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const v2s s = PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
+                const v2s d = (k == 0) ? diag0 : Hold[k - 1];
+                Tpre[k] = PK(I32(d) + I32(s));
+                Epre[k] = PK(I32(E[k]) - I32(vExt));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const v2s s = PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
@@ -238,10 +249,9 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 // Same domain as the max3 variant, but the strips carry H - open and the profile
                 // carries score + open (>= 0), so add and subtract never carry or borrow across
                 // the 16-bit halves and run as full-rate 32-bit VOP2 (v_add_u32 / v_sub_u32).
-                const v2s Tt = PK(I32(d) + I32(s));
-                H = pk_max3f(Tt, E[k], F);
+                H = pk_max3f(Tpre[k], E[k], F);
                 const v2s Ho = PK(I32(H) - I32(vOpen));
-                E[k] = pk_max3f(PK(I32(E[k]) - I32(vExt)), Ho, Ho);
+                E[k] = pk_max3f(Epre[k], Ho, Ho);
                 F = pk_max3f(PK(I32(F) - I32(vExt)), Ho, vZero);
                 Hnew[k] = Ho;
                 Hcur[k] = H;
