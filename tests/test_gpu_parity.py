@@ -654,6 +654,56 @@ def test_banded_matches_full_when_band_is_wide(pkg, orc):
         assert narrow.get_score() <= full
 
 
+# ------------------------------------------------------------------------------- fuzz ----
+def test_fuzz_every_dispatch_path(pkg, orc):
+    """Randomised differential test over the whole batch dispatcher: random mode, free-end set, gap
+    model, matrix, width, length distribution and output kind (records / stats / CIGAR), every
+    result compared with the oracle.  Seeds are fixed; failures print the configuration."""
+    rng = np.random.default_rng(77)
+    mats = [("dna23", pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3), DNA),
+            ("dna11", pkg.Matrix.default(), orc.Matrix.default(), DNA),
+            ("dna54", pkg.Matrix.create(b"ACGTN", 5, -4), orc.Matrix.create("ACGTN", 5, -4), DNA),
+            ("b62", pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt"), AA)]
+    for it in range(60):
+        name, pm, om, alpha = mats[int(rng.integers(0, len(mats)))]
+        mode = int(rng.integers(0, 3))
+        sg = int(rng.integers(1, 16)) if mode == 1 else None
+        open_ = int(rng.choice([0, 1, 2, 5, 11, 20]))
+        ext = int(rng.choice([0, 1, 2, 5]))
+        width = int(rng.choice([0, 16, 32]))
+        kind = ["rec", "stats", "cigar"][int(rng.integers(0, 3))]
+        n = int(rng.choice([1, 2, 7, 33, 300]))
+        lo, hi = [(1, 30), (20, 160), (100, 400), (1, 700)][int(rng.integers(0, 4))]
+        qs = random_seqs(rng, n, lo, hi, alpha)
+        rs = [mutate(rng, q, 0.15, 0.05, alpha) if rng.random() < 0.7 else random_seqs(rng, 1, lo, hi, alpha)[0] for q in qs]
+        b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext)
+        [b.global_, b.semi_global, b.local][mode]()
+        if width:
+            b.solution_width(width)
+        if mode == 1:
+            qg = [t for f, t in ((orc.S1_BEG, "prefix"), (orc.S1_END, "suffix")) if sg & f]
+            dg = [t for f, t in ((orc.S2_BEG, "prefix"), (orc.S2_END, "suffix")) if sg & f]
+            b.allow_query_gaps(qg).allow_ref_gaps(dg)
+            if not qg and not dg:
+                sg = orc.SG_ALL
+        ctx = (it, name, mode, sg, open_, ext, width, kind, n, lo, hi)
+        if kind == "cigar":
+            rec, cig = b.use_trace().build().align_batch_cigar(qs, rs)
+        elif kind == "stats":
+            rec, st = b.use_stats().build().align_batch(qs, rs)
+        else:
+            rec = b.build().align_batch(qs, rs)
+        for k in range(n):
+            w = orc.align(mode, qs[k], rs[k], open_, ext, om, sg_flags=sg if sg is not None else orc.SG_ALL,
+                          stats=kind == "stats", trace=kind == "cigar")
+            assert (rec["score"][k], rec["end_query"][k], rec["end_ref"][k]) == (w.score, w.end_query, w.end_ref), (ctx, k, qs[k], rs[k])
+            assert rec["flags"][k] == 0, ctx
+            if kind == "stats":
+                assert (st["matches"][k], st["similar"][k], st["length"][k]) == (w.matches, w.similar, w.length), (ctx, k)
+            if kind == "cigar":
+                assert cig[k] == orc.cigar(w), (ctx, k, qs[k], rs[k])
+
+
 # ------------------------------------------------------------------ full-size properties ----
 def test_headline_config_properties(pkg, orc):
     """BASELINE config 2 at full size (1M x 150 x 150): sampled oracle parity plus
