@@ -54,3 +54,43 @@ def gather_records(local, counts, dst=0, group=None, async_op=False):
     if async_op:
         return finish, work
     return finish(), None
+
+
+def gather_strings(local_strings, dst=0, group=None):
+    """Gather variable-length byte strings (CIGARs) to `dst` in rank order, two phases:
+    lengths first (fixed width), then the concatenated bytes padded to the longest shard.
+    Returns the full list on `dst`, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    enc = [x if isinstance(x, (bytes, bytearray)) else x.encode() for x in local_strings]
+    lens = torch.tensor([len(x) for x in enc], dtype=torch.int64, device=dev)
+    meta = torch.tensor([len(enc), int(lens.sum().item()) if len(enc) else 0], dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    counts = [int(m[0].item()) for m in metas]
+    nbytes = [int(m[1].item()) for m in metas]
+    max_n, max_b = max(counts), max(nbytes)
+    lens_p = torch.zeros(max_n, dtype=torch.int64, device=dev)
+    lens_p[: len(enc)] = lens
+    body = torch.zeros(max(max_b, 1), dtype=torch.uint8, device=dev)
+    if nbytes[rank]:
+        body[: nbytes[rank]] = torch.frombuffer(bytearray(b"".join(enc)), dtype=torch.uint8).to(dev)
+    lens_all = [torch.empty_like(lens_p) for _ in range(world)] if rank == dst else None
+    body_all = [torch.empty_like(body) for _ in range(world)] if rank == dst else None
+    dist.gather(lens_p, lens_all, dst=dst, group=group)
+    dist.gather(body, body_all, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = []
+    for g in range(world):
+        ls = lens_all[g][: counts[g]].cpu().tolist()
+        raw = body_all[g][: nbytes[g]].cpu().numpy().tobytes()
+        pos = 0
+        for l in ls:
+            out.append(raw[pos:pos + l].decode())
+            pos += l
+    return out

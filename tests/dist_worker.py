@@ -54,6 +54,22 @@ def main():
             cells = np.array(ql, dtype=np.int64) * np.array(rl, dtype=np.int64)
             per = [int(cells[bounds[k]:bounds[k + 1]].sum()) for k in range(world)]
             assert max(per) - min(per) <= 2 * int(cells.max()), per      # balanced to within two pairs
+    # variable-length results (CIGAR strings): two-phase gather restores input order
+    bounds = sharding.shard_bounds_by_cells(ql, rl, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    local = []
+    for k in range(lo, min(hi, lo + 40)):
+        local.append(orc.cigar(orc.align(orc.SG, qs[k], rs[k], 5, 2, om, trace=True)))
+    got = sharding.gather_strings(local, dst=0)
+    if rank == 0:
+        want = []
+        for rk in range(world):
+            for k in range(bounds[rk], min(bounds[rk + 1], bounds[rk] + 40)):
+                want.append(orc.cigar(orc.align(orc.SG, qs[k], rs[k], 5, 2, om, trace=True)))
+        assert got == want
+    else:
+        assert got is None
+    assert sharding.gather_strings([], dst=0) in ([], None)
     dist.barrier()
     if rank == 0:
         print("dist ok world=%d" % world)

@@ -100,6 +100,26 @@ def test_multithread_shared_profile(pkg):
     assert out == [4, 4]
 
 
+def test_scan_and_diag_names_are_aliases(pkg, orc):
+    """`_scan` / `_diag` strategy slots (src/aligner/mod.rs:198-208) resolve to the same kernels; only the
+    strategy predicate differs (src/alignment/mod.rs:446-460)."""
+    rng = np.random.default_rng(909)
+    q = random_seqs(rng, 1, 80, 80)[0]
+    r = mutate(rng, q, 0.1, 0.05)
+    om = orc.Matrix.create("ACGT", 2, -3)
+    for mode in (0, 1, 2):
+        want = orc.align(mode, q, r, 5, 2, om, stats=True)
+        for strat in ("striped", "scan", "diag"):
+            b = pkg.Aligner.new().matrix(pkg.Matrix.create(b"ACGT", 2, -3)).gap_open(5).gap_extend(2).use_stats()
+            [b.global_, b.semi_global, b.local][mode]()
+            getattr(b, strat)()
+            res = b.build().align(q, r)
+            assert (res.get_score(), res.get_end_query(), res.get_end_ref(), res.get_matches(), res.get_length()) == \
+                   (want.score, want.end_query, want.end_ref, want.matches, want.length)
+            assert (res.is_striped(), res.is_scan(), res.is_diag()) == (strat == "striped", strat == "scan", strat == "diag")
+            assert not res.is_blocked() and not res.is_banded()
+
+
 def test_accessor_guards(pkg):
     res = pkg.Aligner.new().build().align(b"ACGT", b"ACGT")
     for f, exc in (("get_matches", pkg.NoStats), ("get_length", pkg.NoStats), ("get_score_table", pkg.NoTable),
