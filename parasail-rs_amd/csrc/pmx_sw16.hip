@@ -88,7 +88,11 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 {
     static_assert(R % 2 == 0, "rows are stored two per dword");
     constexpr bool M3 = VAR >= 1;      // biased unsigned lanes, v_pk_maximum3_f16 as integer max3
-    constexpr bool V2 = VAR == 2;      // + full-rate 32-bit VOP2 add/sub on packed lanes (no cross-half carry)
+    constexpr bool V2 = VAR >= 2;      // + full-rate 32-bit VOP2 add/sub on packed lanes (no cross-half carry)
+    constexpr bool U8 = VAR == 3;      // + one-byte profile entries (score + open fits 0..255): half the LDS, same v_perm count
+    constexpr int EB = U8 ? 1 : 2;     // bytes per profile entry
+    constexpr int WR = U8 ? 4 : 2;     // rows per loaded dword
+    static_assert(!U8 || R % 4 == 0, "byte profile: four rows per dword");
     constexpr int QP = G * R;            // padded query rows per pair
     constexpr int QP2 = QP / 2;          // dwords per profile row
     constexpr int SLOTS = 64 / G;
@@ -98,13 +102,13 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     const int lane = threadIdx.x;
     const int g = lane % G;
     const int slot = lane / G;
-    const int PROF_STRIDE = msize * QP * 2;   // bytes per pair
+    const int PROF_STRIDE = msize * QP * EB;   // bytes per pair
 
     // LDS carve: [prof NP][shared pad row QP*2][rsym NP*RP][mat msize*msize*2][map 256][pair table NP*4 ints]
     // The pad row sits right behind the last pair's profile; pair p reaches it with the symbol
     // value (NP - p) * msize, so no per-pair copy is needed.
     int16_t *prof = reinterpret_cast<int16_t *>(lds);
-    unsigned char *rsym = lds + NP * PROF_STRIDE + QP * 2;
+    unsigned char *rsym = lds + NP * PROF_STRIDE + QP * EB;
     int16_t *mat = reinterpret_cast<int16_t *>(rsym + NP * RP);
     unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
     long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));   // per pair: q offset, qlen, r offset, rlen, pair index
@@ -175,26 +179,31 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 const int p = item / QP2, rp = item - p * QP2;
                 const int q0 = v0[u] ? map[r0[u]] : -1;
                 const int q1 = v1[u] ? map[r1[u]] : -1;
-                int *pp = reinterpret_cast<int *>(prof) + p * (PROF_STRIDE / 4) + rp;
                 for (int sym = 0; sym < msize; ++sym) {
                     const int s0 = ((q0 < 0) ? 0 : mat[q0 * msize + sym]) + (V2 ? open : 0);
                     const int s1 = ((q1 < 0) ? 0 : mat[q1 * msize + sym]) + (V2 ? open : 0);
-                    pp[sym * QP2] = (s0 & 0xFFFF) | (s1 << 16);
+                    if (U8) {
+                        reinterpret_cast<unsigned short *>(lds + p * PROF_STRIDE + sym * QP)[rp] =
+                            (unsigned short)((s0 & 0xFF) | ((s1 & 0xFF) << 8));
+                    } else {
+                        int *pp = reinterpret_cast<int *>(prof) + p * (PROF_STRIDE / 4) + rp;
+                        pp[sym * QP2] = (s0 & 0xFFFF) | (s1 << 16);
+                    }
                 }
             }
         }
     }
-    for (int idx = lane; idx < QP2; idx += 64)
-        reinterpret_cast<int *>(prof)[NP * (PROF_STRIDE / 4) + idx] = V2 ? 0 : FLOOR2;
+    for (int idx = lane; idx < QP * EB / 4; idx += 64)
+        reinterpret_cast<int *>(lds + NP * PROF_STRIDE)[idx] = V2 ? 0 : FLOOR2;
     __syncthreads();
 
     // ---- systolic sweep ---------------------------------------------------------------
     const int pA = 2 * slot, pB = 2 * slot + 1;
-    const unsigned char *profA = lds + pA * PROF_STRIDE + g * (R * 2);
-    const unsigned char *profB = lds + pB * PROF_STRIDE + g * (R * 2);
+    const unsigned char *profA = lds + pA * PROF_STRIDE + g * (R * EB);
+    const unsigned char *profB = lds + pB * PROF_STRIDE + g * (R * EB);
     const unsigned char *rsA = rsym + pA * RP + (G - 1) - g;
     const unsigned char *rsB = rsym + pB * RP + (G - 1) - g;
-    const int SYMSTRIDE = QP * 2;
+    const int SYMSTRIDE = QP * EB;
 
     const v2s vOpen = PK((open & 0xFFFF) | (open << 16));
     const v2s vExt = PK((ext & 0xFFFF) | (ext << 16));
@@ -218,13 +227,13 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     int Hout = HNEUTRAL, Fout = ZERO2;        // last-row H (V2: H - open) and outgoing F of the previous step
     v2s diag0 = PK(HNEUTRAL);                 // H(i0-1, j-1)   (V2: minus open)
 
-    auto load_scores = [&](int symA, int symB, int (&wa)[R / 2], int (&wb)[R / 2]) {
+    auto load_scores = [&](int symA, int symB, int (&wa)[R / WR], int (&wb)[R / WR]) {
         const int *sa = reinterpret_cast<const int *>(profA + symA * SYMSTRIDE);
         const int *sb = reinterpret_cast<const int *>(profB + symB * SYMSTRIDE);
 #pragma unroll
-        for (int k = 0; k < R / 2; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
+        for (int k = 0; k < R / WR; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
     };
-    auto step = [&](const v2s (&Hold)[R], v2s (&Hnew)[R], const int (&wa)[R / 2], const int (&wb)[R / 2]) {
+    auto step = [&](const v2s (&Hold)[R], v2s (&Hnew)[R], const int (&wa)[R / WR], const int (&wb)[R / WR]) {
         const int Hin = group_shift_up<G>(Hout, HNEUTRAL, g); // H(i0-1, j)
         v2s F = PK(group_shift_up<G>(Fout, ZERO2, g));        // F(i0, j)
         v2s colmax = vZero;
@@ -233,7 +242,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         if (V2) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const v2s s = PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
+                const v2s s = U8 ? PK(__builtin_amdgcn_perm(wb[k / 4], wa[k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16)))
+                               : PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
                 const v2s d = (k == 0) ? diag0 : Hold[k - 1];
                 Tpre[k] = PK(I32(d) + I32(s));
                 Epre[k] = PK(I32(E[k]) - I32(vExt));
@@ -242,7 +252,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const v2s s = PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
+            const v2s s = U8 ? PK(__builtin_amdgcn_perm(wb[k / 4], wa[k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16)))
+                               : PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
             const v2s d = (k == 0) ? diag0 : Hold[k - 1];
             v2s H;
             if (V2) {
@@ -304,7 +315,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 
     // software pipeline: scores of step t+1 are fetched from LDS while step t computes
     const int T = (max_rlen + G - 1 + 1) & ~1;           // even number of steps (extra pad column is harmless)
-    int w0a[R / 2], w0b[R / 2], w1a[R / 2], w1b[R / 2];
+    int w0a[R / WR], w0b[R / WR], w1a[R / WR], w1b[R / WR];
     load_scores(rsA[0], rsB[0], w0a, w0b);
     int nsA = rsA[1], nsB = rsB[1];
     for (int t = 0; t < T; t += 2) {
@@ -366,10 +377,10 @@ template <int G, int R, int VAR>
 static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                       pmx_record_t *d_out, hipStream_t stream)
 {
-    constexpr int QP = G * R, NP = 2 * (64 / G);
+    constexpr int QP = G * R, NP = 2 * (64 / G), EB = VAR == 3 ? 1 : 2;
     if (NP * m.msize > 255) return 1;                 // per-pair pad symbol must fit a byte
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
-    const size_t lds = (size_t)NP * m.msize * QP * 2 + (size_t)QP * 2 + (size_t)NP * RP +
+    const size_t lds = (size_t)NP * m.msize * QP * EB + (size_t)QP * EB + (size_t)NP * RP +
                        (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
     if (lds > 160 * 1024) return 1;
     static bool attr_done = false;   // per instantiation
@@ -403,12 +414,19 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
     // 32-bit add/sub variant: score + open must be non-negative, and E - extend must not borrow
     if (var == 1 && m.min + open >= 0 && open + ext <= 1024) var = 2;
     if (force && atoi(force) < var) var = atoi(force);
+    const bool u8ok = var == 2 && m.max + open <= 255 && !getenv("PMX_SW16_NO_U8");
 #define TRY(GG, RR, NAME)                                                       \
     if (q <= (GG) * (RR)) {                                                     \
-        int rc = var == 2 ? launch_one<GG, RR, 2>(b, m, open, ext, d_out, stream)  \
+        int rc = (u8ok && (RR) % 4 == 0) ? launch_one<GG, ((RR) % 4 == 0 ? (RR) : 4), 3>(b, m, open, ext, d_out, stream)  \
+               : var == 2 ? launch_one<GG, RR, 2>(b, m, open, ext, d_out, stream)  \
                : var == 1 ? launch_one<GG, RR, 1>(b, m, open, ext, d_out, stream)  \
                           : launch_one<GG, RR, 0>(b, m, open, ext, d_out, stream); \
         if (rc <= 0) { if (kernel_name) *kernel_name = var == 2 ? NAME "/max3+vop2" : var == 1 ? NAME "/max3" : NAME; return rc; } \
+    }
+    // byte profile + 20 rows per lane: half the fill/drain and per-step overhead of <16,10> at the same LDS
+    if (u8ok && q <= 160) {
+        int rc = launch_one<8, 20, 3>(b, m, open, ext, d_out, stream);
+        if (rc <= 0) { if (kernel_name) *kernel_name = "pmx_sw16_kernel<8,20>/max3+vop2+u8"; return rc; }
     }
     TRY(16, 10, "pmx_sw16_kernel<16,10>")
     TRY(16, 16, "pmx_sw16_kernel<16,16>")
