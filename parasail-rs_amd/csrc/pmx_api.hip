@@ -113,8 +113,8 @@ extern "C" parasail_matrix_t *parasail_matrix_create(const char *alphabet, const
     return publish(b);
 }
 
-static parasail_matrix_t g_blosum62;
-static std::vector<int> g_blosum62_mapper;
+static parasail_matrix_t g_blosum62, g_nuc44;
+static std::vector<int> g_blosum62_mapper, g_nuc44_mapper;
 static std::once_flag g_builtin_once;
 static void init_builtins()
 {
@@ -126,6 +126,11 @@ static void init_builtins()
     g_blosum62.size = 24; g_blosum62.max = 11; g_blosum62.min = -4;
     g_blosum62.user_matrix = nullptr; g_blosum62.type = PARASAIL_MATRIX_TYPE_SQUARE;
     g_blosum62.length = 24; g_blosum62.alphabet = pmx_blosum62_alphabet; g_blosum62.query = nullptr;
+    fill_mapper(g_nuc44_mapper, std::string(pmx_nuc44_alphabet, 15), 15);
+    g_nuc44_mapper[(unsigned char)'*'] = 15;
+    g_nuc44.name = "nuc44"; g_nuc44.matrix = pmx_nuc44_scores; g_nuc44.mapper = g_nuc44_mapper.data();
+    g_nuc44.size = 16; g_nuc44.max = 5; g_nuc44.min = -5; g_nuc44.user_matrix = nullptr;
+    g_nuc44.type = PARASAIL_MATRIX_TYPE_SQUARE; g_nuc44.length = 16; g_nuc44.alphabet = pmx_nuc44_alphabet; g_nuc44.query = nullptr;
 }
 
 // src/matrix/mod.rs:57-73: NULL -> Error::FailedLookup.  Built-ins are static, never freed.
@@ -136,6 +141,7 @@ extern "C" const parasail_matrix_t *parasail_matrix_lookup(const char *matrixnam
     std::string s(matrixname);
     for (auto &c : s) c = (char)tolower((unsigned char)c);
     if (s == "blosum62") return &g_blosum62;
+    if (s == "nuc44") return &g_nuc44;
     return nullptr;
 }
 

@@ -157,6 +157,17 @@ def test_blosum62_matches_fixture(pkg, orc):
     assert (ff.to_numpy() == f.scores).all() and (ff.mapper() == f.mapper).all()
 
 
+def test_nuc44_matches_reference_fixture(pkg, orc):
+    """built-in "nuc44" = the reference's tests/square.txt without its extra U row/column"""
+    n = pkg.Matrix.from_name("nuc44")
+    sq = orc.Matrix.from_file(os.path.join(ROOT, "tests/golden/square.txt"))
+    keep = [i for i, c in enumerate(sq.alphabet) if c != "U"]
+    assert (n.to_numpy() == sq.scores[np.ix_(keep, keep)]).all()
+    assert n.size == 16 and n.mapper()[ord("a")] == 0 and n.mapper()[ord("N")] == 14 and n.mapper()[ord("U")] == 15
+    with pytest.raises(pkg.NotBuiltIn):
+        n.set_value(0, 0, 1)
+
+
 def test_profile_construction(pkg):
     """tests/test_parasail.rs:36-45, :758-765 and src/profile/mod.rs:298-358"""
     q = b"ATGGCACTATAA"
