@@ -6,6 +6,9 @@
 
 #define PMX_MAX_FAST_MSIZE 32      // fast kernels stage the matrix in LDS as int16[msize*msize]
 
+// Raise the dynamic-LDS limit of a kernel once per (kernel, device); thread-safe.
+int pmx_ensure_lds_attr(const void *kernel);
+
 // Device-side view of a substitution matrix (built once per parasail_matrix_t, cached).
 struct PmxDevMatrix {
     const int16_t *scores;   // [msize*msize], scores[qsym*msize + rsym]   (device)

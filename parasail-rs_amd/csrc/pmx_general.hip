@@ -294,6 +294,24 @@ void pmx_general_kernel(const PmxGeneralArgs a)
     }
 }
 
+#include <mutex>
+#include <set>
+#include <utility>
+int pmx_ensure_lds_attr(const void *kernel)
+{
+    static std::mutex mx;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return -(int)e;
+    std::lock_guard<std::mutex> lk(mx);
+    if (done.count({kernel, dev})) return 0;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return -(int)e;
+    done.insert({kernel, dev});
+    return 0;
+}
+
 int pmx_launch_general(const PmxGeneralArgs &a_in, bool want_stats, hipStream_t stream)
 {
     if (a_in.n <= 0) return 0;
@@ -302,15 +320,10 @@ int pmx_launch_general(const PmxGeneralArgs &a_in, bool want_stats, hipStream_t 
     if (lds > 160 * 1024) return 1;
     a.trace_lds = 0;
     if (a.trace_table && lds + (size_t)64 * a.max_rlen + 32 <= 96 * 1024) { a.trace_lds = 1; lds += (size_t)64 * a.max_rlen + 32; }
-    static bool attr_done = false;
-    if (!attr_done) {
+    {
         const void *fns[4] = {(const void *)&pmx_general_kernel<true, true>, (const void *)&pmx_general_kernel<true, false>,
                               (const void *)&pmx_general_kernel<false, true>, (const void *)&pmx_general_kernel<false, false>};
-        for (const void *f : fns) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return -(int)e;
-        }
-        attr_done = true;
+        for (const void *f : fns) { const int rc = pmx_ensure_lds_attr(f); if (rc) return rc; }
     }
     const bool out = a.score_table || a.trace_table || a.score_row || a.score_col ||
                      a.matches_table || a.similar_table || a.length_table;

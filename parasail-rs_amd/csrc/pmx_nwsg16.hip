@@ -365,13 +365,7 @@ static int launch_nwsg(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
     const size_t lds = (size_t)NP * (m.msize + 1) * QP * 2 + (size_t)NP * RP +
                        (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
     if (lds > 160 * 1024) return 1;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_nwsg16_kernel<G, R>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return -(int)e;
-        attr_done = true;
-    }
+    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16_kernel<G, R>)); if (rc) return rc; }
     const bool sg = mode == PMX_MODE_SG;
     const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);

@@ -336,13 +336,7 @@ static int launch_stats(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     const size_t lds = (size_t)nprof * (m.msize + 1) * QP * 6 + (size_t)NP * RP +
                        (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
     if (lds > 160 * 1024) return 1;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_stats16_kernel<G, R, WAVES, SW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return -(int)e;
-        attr_done = true;
-    }
+    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_stats16_kernel<G, R, WAVES, SW>)); if (rc) return rc; }
     const bool sg = mode == PMX_MODE_SG;
     const int col_pen = SW ? 0 : !(sg && (sg_flags & PMX_SG_QB)), row_pen = SW ? 0 : !(sg && (sg_flags & PMX_SG_DB));
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);

@@ -383,13 +383,7 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
     const size_t lds = (size_t)NP * m.msize * QP * EB + (size_t)QP * EB + (size_t)NP * RP +
                        (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
     if (lds > 160 * 1024) return 1;
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pmx_sw16_kernel<G, R, VAR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return -(int)e;
-        attr_done = true;
-    }
+    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_sw16_kernel<G, R, VAR>)); if (rc) return rc; }
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
     hipLaunchKernelGGL((pmx_sw16_kernel<G, R, VAR>), dim3((unsigned)blocks), dim3(64), lds, stream,
