@@ -67,10 +67,13 @@ __device__ __forceinline__ v2s pk_subus(v2s a, v2s b)      // v_pk_sub_u16 clamp
 {
     return __builtin_bit_cast(v2s, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, b)));
 }
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2s pk_max3f(v2s a, v2s b, v2s c)   // integer max3 on {0} U [1024, 31743] patterns
 {
-    int r;
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(__builtin_bit_cast(int, a)), "v"(__builtin_bit_cast(int, b)), "v"(__builtin_bit_cast(int, c)));
+    // fmaximum(fmaximum(a, b), c) on v2f16 selects v_pk_maximum3_f16 on gfx950.  A builtin rather
+    // than inline asm: the hazard recognizer pads every inline-asm result with an s_nop.
+    const v2h r = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(v2h, a), __builtin_bit_cast(v2h, b)),
+                                                __builtin_bit_cast(v2h, c));
     return __builtin_bit_cast(v2s, r);
 }
 #define FLOOR2 0x80008000   // both halves = -32768 = "zero" of the offset domain
@@ -82,14 +85,15 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                      long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
                      int msize, int open, int ext, int RP /* rsym stride, bytes */,
                      int q_shared /* > 0: every pair uses qbuf[0..q_shared) */,
-                     int limit /* M3 only: biased scores at or above this are flagged for a re-run */,
+                     int limit /* M3 only: biased scores at or above this are flagged for a re-run (SK: growth already taken off) */,
                      const unsigned *__restrict__ perm,
                      pmx_record_t *__restrict__ out)
 {
     static_assert(R % 2 == 0, "rows are stored two per dword");
     constexpr bool M3 = VAR >= 1;      // biased unsigned lanes, v_pk_maximum3_f16 as integer max3
     constexpr bool V2 = VAR >= 2;      // + full-rate 32-bit VOP2 add/sub on packed lanes (no cross-half carry)
-    constexpr bool U8 = VAR == 3;      // + one-byte profile entries (score + open fits 0..255): half the LDS, same v_perm count
+    constexpr bool U8 = VAR == 3 || VAR == 5;   // + one-byte profile entries (score + open fits 0..255): half the LDS, same v_perm count
+    constexpr bool SK = VAR >= 4;      // + column-skewed values (everything in column j carries +(j+G)*ext): E needs no subtract
     constexpr int EB = U8 ? 1 : 2;     // bytes per profile entry
     constexpr int WR = U8 ? 4 : 2;     // rows per loaded dword
     static_assert(!U8 || R % 4 == 0, "byte profile: four rows per dword");
@@ -217,15 +221,25 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     // values never have to be moved between registers.
     v2s HA[R], HB[R], E[R], Hsave[R];
     // V2: the strips hold H - open (the diagonal source), E starts at its exact value -open
-    const v2s vInitH = V2 ? PK(ZERO2 - I32(vOpen)) : vZero;
+    // SK: a value of column j is stored as value + (j + G) * ext.  Then E(j+1) = max(E(j) - ext, H(j) - open)
+    // becomes E~(j+1) = max(E~(j), H~(j) - (open - ext)): the per-cell subtract of the E extension is gone.
+    // F keeps an extra +ext ("F^"), so the same X = H~ - (open - ext) serves E, F and the strip (the next
+    // column's diagonal source; the profile carries score + open as before).  Values only grow by
+    // (steps + G) * ext; the host takes that growth off the re-run limit.  Needs open >= ext.
+    const int skew0 = SK ? (((G - g) * ext) & 0xFFFF) * 0x00010001 : 0;      // this lane's first column is j = -g
+    const v2s vC = PK(I32(vOpen) - I32(vExt));                               // open - ext, per half
+    const v2s vInitH = V2 ? PK(ZERO2 - I32(vOpen) + skew0) : vZero;
 #pragma unroll
     for (int k = 0; k < R; ++k) { HA[k] = vInitH; HB[k] = vInitH; E[k] = V2 ? vInitH : (M3 ? PK(0) : vZero); Hsave[k] = vZero; }
-    v2s best = vZero;
+    v2s best = PK(ZERO2 + skew0);
     int bestcol = 0;
     int jj = ((-g) & 0xFFFF) * 0x00010001;    // packed column index of this lane
+    int Zv = ZERO2 + skew0 + I32(vExt);       // SK: "F^ = 0" of the current column; += ext per step
     const int HNEUTRAL = V2 ? ZERO2 - I32(vOpen) : ZERO2;
-    int Hout = HNEUTRAL, Fout = ZERO2;        // last-row H (V2: H - open) and outgoing F of the previous step
-    v2s diag0 = PK(HNEUTRAL);                 // H(i0-1, j-1)   (V2: minus open)
+    // last-row H (V2: H - open) and outgoing F of the previous step; SK: what lane g+1 reads at step 0
+    // belongs to ITS first column -(g+1), one ext below this lane's own column
+    int Hout = SK ? Zv - I32(vExt) - I32(vOpen) : HNEUTRAL, Fout = SK ? Zv - I32(vExt) : ZERO2;
+    v2s diag0 = PK(SK ? I32(vInitH) : HNEUTRAL);   // H(i0-1, j-1)   (V2: minus open)
 
     auto load_scores = [&](int symA, int symB, int (&wa)[R / WR], int (&wb)[R / WR]) {
         const int *sa = reinterpret_cast<const int *>(profA + symA * SYMSTRIDE);
@@ -234,9 +248,9 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         for (int k = 0; k < R / WR; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
     };
     auto step = [&](const v2s (&Hold)[R], v2s (&Hnew)[R], const int (&wa)[R / WR], const int (&wb)[R / WR]) {
-        const int Hin = group_shift_up<G>(Hout, HNEUTRAL, g); // H(i0-1, j)
-        v2s F = PK(group_shift_up<G>(Fout, ZERO2, g));        // F(i0, j)
-        v2s colmax = vZero;
+        const int Hin = group_shift_up<G>(Hout, SK ? Zv - I32(vOpen) : HNEUTRAL, g); // H(i0-1, j)
+        v2s F = PK(group_shift_up<G>(Fout, SK ? Zv : ZERO2, g));                       // F(i0, j)
+        v2s colmax = SK ? PK(0) : vZero;
         v2s Hcur[R];                                           // V2 only: this column's H (the strips hold H - open)
         v2s Tpre[R], Epre[R];                                  // V2 only: hoisted independent adds / subtracts
         if (V2) {
@@ -246,7 +260,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                                : PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
                 const v2s d = (k == 0) ? diag0 : Hold[k - 1];
                 Tpre[k] = PK(I32(d) + I32(s));
-                Epre[k] = PK(I32(E[k]) - I32(vExt));
+                if (!SK) Epre[k] = PK(I32(E[k]) - I32(vExt));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -256,7 +270,16 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                                : PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
             const v2s d = (k == 0) ? diag0 : Hold[k - 1];
             v2s H;
-            if (V2) {
+            if (SK) {
+                const v2s Fe = PK(I32(F) - I32(vExt));            // F~ of this row (F^ - ext), also F^'s extension
+                H = pk_max3f(Tpre[k], E[k], Fe);
+                const v2s X = PK(I32(H) - I32(vC));
+                E[k] = pk_max3f(E[k], X, X);
+                F = pk_max3f(Fe, X, PK(Zv));
+                Hnew[k] = X;
+                Hcur[k] = H;
+                if (k & 1) colmax = pk_max3f(colmax, Hcur[k - 1], H);
+            } else if (V2) {
                 // Same domain as the max3 variant, but the strips carry H - open and the profile
                 // carries score + open (>= 0), so add and subtract never carry or borrow across
                 // the 16-bit halves and run as full-rate 32-bit VOP2 (v_add_u32 / v_sub_u32).
@@ -309,7 +332,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hs) : "v"(m), "v"(I32(V2 ? Hcur[k] : Hnew[k])), "v"(I32(Hsave[k])));
             Hsave[k] = PK(hs);
         }
-        best = nb;
+        best = SK ? PK(I32(nb) + I32(vExt)) : nb;                           // SK: carried into the next column's skew
+        if (SK) Zv += I32(vExt);
         jj = __builtin_bit_cast(int, __builtin_bit_cast(v2u, jj) + one2);   // per-half add: no carry into pair B
     };
 
@@ -335,14 +359,17 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     unsigned long long keyA, keyB;
     {
         const int bA = (short)(I32(best) & 0xFFFF), bB = (short)(I32(best) >> 16);
+        const unsigned cA = bestcol & 0xFFFF, cB = (unsigned)bestcol >> 16;
+        // SK: `best` was carried through T - (save step) columns after the strip was saved
+        const int tA = SK ? bA - (T - ((int)cA + g)) * ext : bA, tB = SK ? bB - (T - ((int)cB + g)) * ext : bB;
         int kA = 0, kB = 0;
 #pragma unroll
         for (int k = R - 1; k >= 0; --k) {
-            if ((short)(I32(Hsave[k]) & 0xFFFF) == bA) kA = k;
-            if ((short)(I32(Hsave[k]) >> 16) == bB) kB = k;
+            if ((short)(I32(Hsave[k]) & 0xFFFF) == tA) kA = k;
+            if ((short)(I32(Hsave[k]) >> 16) == tB) kB = k;
         }
-        const unsigned sA = (unsigned)(bA - (M3 ? M3_BIAS : -32768)), sB = (unsigned)(bB - (M3 ? M3_BIAS : -32768));
-        const unsigned cA = bestcol & 0xFFFF, cB = (unsigned)bestcol >> 16;
+        const int unskew = SK ? (G - g + T) * ext : 0;
+        const unsigned sA = (unsigned)(bA - unskew - (M3 ? M3_BIAS : -32768)), sB = (unsigned)(bB - unskew - (M3 ? M3_BIAS : -32768));
         const unsigned rA = g * R + kA, rB = g * R + kB;
         keyA = ((unsigned long long)sA << 32) | ((0xFFFFu - cA) << 16) | (0xFFFFu - rA);
         keyB = ((unsigned long long)sB << 32) | ((0xFFFFu - cB) << 16) | (0xFFFFu - rB);
@@ -377,7 +404,7 @@ template <int G, int R, int VAR>
 static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                       pmx_record_t *d_out, hipStream_t stream)
 {
-    constexpr int QP = G * R, NP = 2 * (64 / G), EB = VAR == 3 ? 1 : 2;
+    constexpr int QP = G * R, NP = 2 * (64 / G), EB = (VAR == 3 || VAR == 5) ? 1 : 2;
     if (NP * m.msize > 255) return 1;                 // per-pair pad symbol must fit a byte
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
     const size_t lds = (size_t)NP * m.msize * QP * EB + (size_t)QP * EB + (size_t)NP * RP +
@@ -388,7 +415,7 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
     if (blocks <= 0) return 0;
     hipLaunchKernelGGL((pmx_sw16_kernel<G, R, VAR>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
-                       m.msize, open, ext, RP, b.q_shared, M3_LIMIT(m.max), b.perm, d_out);
+                       m.msize, open, ext, RP, b.q_shared, M3_LIMIT(m.max) - (VAR >= 4 ? (b.max_rlen + 2 * G + 4) * ext : 0), b.perm, d_out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
@@ -409,18 +436,27 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
     if (var == 1 && m.min + open >= 0 && open + ext <= 1024) var = 2;
     if (force && atoi(force) < var) var = atoi(force);
     const bool u8ok = var == 2 && m.max + open <= 255 && !getenv("PMX_SW16_NO_U8");
+    // column-skewed variant: values grow by (columns + 2 G + 4) * ext; use it only when no feasible
+    // score can reach the correspondingly lower re-run limit
+    const long long feasible = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0);
+    const bool sk = var == 2 && open >= ext && !getenv("PMX_SW16_NO_SKEW") &&
+                    feasible + M3_BIAS < (long long)M3_LIMIT(m.max) - (long long)(b.max_rlen + 2 * 64 + 4) * ext;
 #define TRY(GG, RR, NAME)                                                       \
     if (q <= (GG) * (RR)) {                                                     \
-        int rc = (u8ok && (RR) % 4 == 0) ? launch_one<GG, ((RR) % 4 == 0 ? (RR) : 4), 3>(b, m, open, ext, d_out, stream)  \
+        constexpr int R4 = (RR) % 4 == 0 ? (RR) : 4;                            \
+        const bool u8 = u8ok && (RR) % 4 == 0;                                  \
+        int rc = (u8 && sk) ? launch_one<GG, R4, 5>(b, m, open, ext, d_out, stream)  \
+               : u8 ? launch_one<GG, R4, 3>(b, m, open, ext, d_out, stream)     \
+               : (var == 2 && sk) ? launch_one<GG, RR, 4>(b, m, open, ext, d_out, stream)  \
                : var == 2 ? launch_one<GG, RR, 2>(b, m, open, ext, d_out, stream)  \
                : var == 1 ? launch_one<GG, RR, 1>(b, m, open, ext, d_out, stream)  \
                           : launch_one<GG, RR, 0>(b, m, open, ext, d_out, stream); \
-        if (rc <= 0) { if (kernel_name) *kernel_name = var == 2 ? NAME "/max3+vop2" : var == 1 ? NAME "/max3" : NAME; return rc; } \
+        if (rc <= 0) { if (kernel_name) *kernel_name = var == 2 ? (sk ? NAME "/max3+vop2+skew" : NAME "/max3+vop2") : var == 1 ? NAME "/max3" : NAME; return rc; } \
     }
     // byte profile + 20 rows per lane: half the fill/drain and per-step overhead of <16,10> at the same LDS
     if (u8ok && q <= 160) {
-        int rc = launch_one<8, 20, 3>(b, m, open, ext, d_out, stream);
-        if (rc <= 0) { if (kernel_name) *kernel_name = "pmx_sw16_kernel<8,20>/max3+vop2+u8"; return rc; }
+        int rc = sk ? launch_one<8, 20, 5>(b, m, open, ext, d_out, stream) : launch_one<8, 20, 3>(b, m, open, ext, d_out, stream);
+        if (rc <= 0) { if (kernel_name) *kernel_name = sk ? "pmx_sw16_kernel<8,20>/max3+vop2+u8+skew" : "pmx_sw16_kernel<8,20>/max3+vop2+u8"; return rc; }
     }
     TRY(16, 10, "pmx_sw16_kernel<16,10>")
     TRY(16, 16, "pmx_sw16_kernel<16,16>")

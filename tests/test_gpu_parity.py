@@ -217,6 +217,28 @@ def test_sw16_file_matrix_asymmetric(pkg, orc):
     _fast_case(pkg, orc, qs, rs, 5, 2, pm, om)
 
 
+@pytest.mark.parametrize("env", [{}, {"PMX_SW16_NO_SKEW": "1"}, {"PMX_SW16_NO_U8": "1"},
+                                 {"PMX_SW16_NO_U8": "1", "PMX_SW16_NO_SKEW": "1"},
+                                 {"PMX_SW16_VARIANT": "1"}, {"PMX_SW16_VARIANT": "0"}])
+def test_sw16_every_arithmetic_variant(pkg, orc, monkeypatch, env):
+    """the six arithmetic variants of the hot kernel (skewed / byte profile / VOP2 / max3 / saturating) agree with the oracle"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(1460)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 600, 1, 160)
+    rs = [mutate(rng, q, 0.1, 0.05) if rng.random() < 0.6 else random_seqs(rng, 1, 1, 400)[0] for q in qs]
+    for gaps in ((5, 2), (2, 2), (7, 0), (0, 0)):
+        _fast_case(pkg, orc, qs, rs, gaps[0], gaps[1], pm, om)
+    qs = random_seqs(rng, 60, 100, 700)
+    rs = [mutate(rng, q, 0.05, 0.05) for q in qs]                    # long, high-scoring
+    _fast_case(pkg, orc, qs, rs, 5, 2, pm, om)
+    bm, bo = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    qs = random_seqs(rng, 100, 30, 256, AA)
+    rs = [mutate(rng, q, 0.3, 0.05, AA) for q in qs]
+    _fast_case(pkg, orc, qs, rs, 11, 1, bm, bo)
+
+
 def test_sw16_saturating_int16_variant(pkg, orc):
     """scores too large for the max3 lanes (matrix max > 2048) take the saturating-int16 variant"""
     rng = np.random.default_rng(1450)
