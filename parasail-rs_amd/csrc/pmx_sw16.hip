@@ -89,15 +89,14 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                      const unsigned *__restrict__ perm,
                      pmx_record_t *__restrict__ out)
 {
-    static_assert(R % 2 == 0, "rows are stored two per dword");
     constexpr bool M3 = VAR >= 1;      // biased unsigned lanes, v_pk_maximum3_f16 as integer max3
     constexpr bool V2 = VAR >= 2;      // + full-rate 32-bit VOP2 add/sub on packed lanes (no cross-half carry)
     constexpr bool U8 = VAR == 3 || VAR == 5;   // + one-byte profile entries (score + open fits 0..255): half the LDS, same v_perm count
     constexpr bool SK = VAR >= 4;      // + column-skewed values (everything in column j carries +(j+G)*ext): E needs no subtract
     constexpr int EB = U8 ? 1 : 2;     // bytes per profile entry
     constexpr int WR = U8 ? 4 : 2;     // rows per loaded dword
-    static_assert(!U8 || R % 4 == 0, "byte profile: four rows per dword");
-    constexpr int QP = G * R;            // padded query rows per pair
+    constexpr int RS = (R + WR - 1) / WR * WR;   // profile rows reserved per lane (whole dwords); rows R..RS-1 are unused
+    constexpr int QP = G * RS;           // profile rows per pair (lane l, row k sits at l * RS + k)
     constexpr int QP2 = QP / 2;          // dwords per profile row
     constexpr int SLOTS = 64 / G;
     constexpr int NP = 2 * SLOTS;        // pairs per wave
@@ -172,9 +171,13 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
             const int p = min(item / QP2, NP - 1), rp = item - p * QP2;
             const int ql = (int)ptab[5 * p + 1];
             const uint8_t *qp = qbase + ptab[5 * p + 0];
-            v0[u] = item < NP * QP2 && 2 * rp < ql; v1[u] = item < NP * QP2 && 2 * rp + 1 < ql;
-            r0[u] = v0[u] ? qp[2 * rp] : (unsigned char)0;
-            r1[u] = v1[u] ? qp[2 * rp + 1] : (unsigned char)0;
+            // profile position -> query row (lane l keeps rows [l * R, l * R + R) at positions l * RS + k)
+            const int p0 = 2 * rp, p1 = 2 * rp + 1;
+            const int k0 = p0 % RS, k1 = p1 % RS;
+            const int row0 = (p0 / RS) * R + k0, row1 = (p1 / RS) * R + k1;
+            v0[u] = item < NP * QP2 && k0 < R && row0 < ql; v1[u] = item < NP * QP2 && k1 < R && row1 < ql;
+            r0[u] = v0[u] ? qp[row0] : (unsigned char)0;
+            r1[u] = v1[u] ? qp[row1] : (unsigned char)0;
         }
 #pragma unroll
         for (int u = 0; u < QB; ++u) {
@@ -203,8 +206,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 
     // ---- systolic sweep ---------------------------------------------------------------
     const int pA = 2 * slot, pB = 2 * slot + 1;
-    const unsigned char *profA = lds + pA * PROF_STRIDE + g * (R * EB);
-    const unsigned char *profB = lds + pB * PROF_STRIDE + g * (R * EB);
+    const unsigned char *profA = lds + pA * PROF_STRIDE + g * (RS * EB);
+    const unsigned char *profB = lds + pB * PROF_STRIDE + g * (RS * EB);
     const unsigned char *rsA = rsym + pA * RP + (G - 1) - g;
     const unsigned char *rsB = rsym + pB * RP + (G - 1) - g;
     const int SYMSTRIDE = QP * EB;
@@ -241,13 +244,13 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     int Hout = SK ? Zv - I32(vExt) - I32(vOpen) : HNEUTRAL, Fout = SK ? Zv - I32(vExt) : ZERO2;
     v2s diag0 = PK(SK ? I32(vInitH) : HNEUTRAL);   // H(i0-1, j-1)   (V2: minus open)
 
-    auto load_scores = [&](int symA, int symB, int (&wa)[R / WR], int (&wb)[R / WR]) {
+    auto load_scores = [&](int symA, int symB, int (&wa)[RS / WR], int (&wb)[RS / WR]) {
         const int *sa = reinterpret_cast<const int *>(profA + symA * SYMSTRIDE);
         const int *sb = reinterpret_cast<const int *>(profB + symB * SYMSTRIDE);
 #pragma unroll
-        for (int k = 0; k < R / WR; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
+        for (int k = 0; k < RS / WR; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
     };
-    auto step = [&](const v2s (&Hold)[R], v2s (&Hnew)[R], const int (&wa)[R / WR], const int (&wb)[R / WR]) {
+    auto step = [&](const v2s (&Hold)[R], v2s (&Hnew)[R], const int (&wa)[RS / WR], const int (&wb)[RS / WR]) {
         const int Hin = group_shift_up<G>(Hout, SK ? Zv - I32(vOpen) : HNEUTRAL, g); // H(i0-1, j)
         v2s F = PK(group_shift_up<G>(Fout, SK ? Zv : ZERO2, g));                       // F(i0, j)
         v2s colmax = SK ? PK(0) : vZero;
@@ -279,6 +282,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 Hnew[k] = X;
                 Hcur[k] = H;
                 if (k & 1) colmax = pk_max3f(colmax, Hcur[k - 1], H);
+                else if (k == R - 1) colmax = pk_max3f(colmax, H, H);
             } else if (V2) {
                 // Same domain as the max3 variant, but the strips carry H - open and the profile
                 // carries score + open (>= 0), so add and subtract never carry or borrow across
@@ -290,6 +294,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 Hnew[k] = Ho;
                 Hcur[k] = H;
                 if (k & 1) colmax = pk_max3f(colmax, Hcur[k - 1], H);
+                else if (k == R - 1) colmax = pk_max3f(colmax, H, H);
             } else if (M3) {
                 // Biased unsigned lanes: every live value is 0 or in [1024, 31743], where the bit
                 // patterns of non-negative f16 order like integers, so v_pk_maximum3_f16 is an exact
@@ -302,6 +307,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 F = pk_max3f(pk_subus(F, vExt), Ho, vZero);
                 Hnew[k] = H;
                 if (k & 1) colmax = pk_max3f(colmax, Hnew[k - 1], H);
+                else if (k == R - 1) colmax = pk_max3f(colmax, H, H);
             } else {
                 H = pk_adds(d, s);
                 H = pk_max(H, E[k]);
@@ -339,7 +345,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 
     // software pipeline: scores of step t+1 are fetched from LDS while step t computes
     const int T = (max_rlen + G - 1 + 1) & ~1;           // even number of steps (extra pad column is harmless)
-    int w0a[R / WR], w0b[R / WR], w1a[R / WR], w1b[R / WR];
+    int w0a[RS / WR], w0b[RS / WR], w1a[RS / WR], w1b[RS / WR];
     load_scores(rsA[0], rsB[0], w0a, w0b);
     int nsA = rsA[1], nsB = rsB[1];
     for (int t = 0; t < T; t += 2) {
@@ -404,7 +410,8 @@ template <int G, int R, int VAR>
 static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                       pmx_record_t *d_out, hipStream_t stream)
 {
-    constexpr int QP = G * R, NP = 2 * (64 / G), EB = (VAR == 3 || VAR == 5) ? 1 : 2;
+    constexpr int EB = (VAR == 3 || VAR == 5) ? 1 : 2, WR = 4 / EB, RS = (R + WR - 1) / WR * WR;
+    constexpr int QP = G * RS, NP = 2 * (64 / G);
     if (NP * m.msize > 255) return 1;                 // per-pair pad symbol must fit a byte
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
     const size_t lds = (size_t)NP * m.msize * QP * EB + (size_t)QP * EB + (size_t)NP * RP +
@@ -453,11 +460,15 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                           : launch_one<GG, RR, 0>(b, m, open, ext, d_out, stream); \
         if (rc <= 0) { if (kernel_name) *kernel_name = var == 2 ? (sk ? NAME "/max3+vop2+skew" : NAME "/max3+vop2") : var == 1 ? NAME "/max3" : NAME; return rc; } \
     }
-    // byte profile + 20 rows per lane: half the fill/drain and per-step overhead of <16,10> at the same LDS
-    if (u8ok && q <= 160) {
-        int rc = sk ? launch_one<8, 20, 5>(b, m, open, ext, d_out, stream) : launch_one<8, 20, 3>(b, m, open, ext, d_out, stream);
-        if (rc <= 0) { if (kernel_name) *kernel_name = sk ? "pmx_sw16_kernel<8,20>/max3+vop2+u8+skew" : "pmx_sw16_kernel<8,20>/max3+vop2+u8"; return rc; }
+    // byte profile, 8 lanes per pair: half the fill/drain and per-step overhead of <16,10> at the same LDS;
+    // rows per lane chosen for the common read lengths (100, 125, 150) so that few rows are padding
+#define TRY8(RR)                                                                \
+    if (u8ok && q <= 8 * (RR)) {                                                \
+        int rc = sk ? launch_one<8, RR, 5>(b, m, open, ext, d_out, stream) : launch_one<8, RR, 3>(b, m, open, ext, d_out, stream); \
+        if (rc <= 0) { if (kernel_name) *kernel_name = sk ? "pmx_sw16_kernel<8," #RR ">/max3+vop2+u8+skew" : "pmx_sw16_kernel<8," #RR ">/max3+vop2+u8"; return rc; } \
     }
+    TRY8(13) TRY8(16) TRY8(19) TRY8(20)
+#undef TRY8
     TRY(16, 10, "pmx_sw16_kernel<16,10>")
     TRY(16, 16, "pmx_sw16_kernel<16,16>")
     TRY(32, 10, "pmx_sw16_kernel<32,10>")

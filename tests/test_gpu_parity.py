@@ -230,6 +230,12 @@ def test_sw16_every_arithmetic_variant(pkg, orc, monkeypatch, env):
     rs = [mutate(rng, q, 0.1, 0.05) if rng.random() < 0.6 else random_seqs(rng, 1, 1, 400)[0] for q in qs]
     for gaps in ((5, 2), (2, 2), (7, 0), (0, 0)):
         _fast_case(pkg, orc, qs, rs, gaps[0], gaps[1], pm, om)
+    for qmax in (100, 104, 125, 128, 150, 152):                      # the 8-lane shapes <8,13> <8,16> <8,19>
+        qs = random_seqs(rng, 300, qmax - 30, qmax)
+        qs[0] = random_seqs(rng, 1, qmax, qmax)[0]
+        rs = [mutate(rng, q, 0.1, 0.05) if rng.random() < 0.7 else random_seqs(rng, 1, 1, 200)[0] for q in qs]
+        rs[0] = qs[0]
+        _fast_case(pkg, orc, qs, rs, 5, 2, pm, om)
     qs = random_seqs(rng, 60, 100, 700)
     rs = [mutate(rng, q, 0.05, 0.05) for q in qs]                    # long, high-scoring
     _fast_case(pkg, orc, qs, rs, 5, 2, pm, om)
