@@ -139,24 +139,27 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     int max_rlen = 0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) max_rlen = max(max_rlen, (int)ptab[5 * p + 3]);
-    // Global loads are issued in batches of UB independent loads per lane before anything consumes
-    // them: the prologue is latency-bound otherwise (one HBM/L2 round trip per loop iteration).
-    constexpr int UB = 8;
-    for (int item0 = 0; item0 < NP * RP; item0 += 64 * UB) {
-        unsigned char raw[UB]; int pad[UB]; bool ok[UB];
+    // Pairs in batches of UB, lanes over positions: UB independent global loads per lane are in
+    // flight before anything consumes them (the prologue is latency-bound otherwise), and no
+    // index needs a division.
+    constexpr int UB = NP < 8 ? NP : 8;
+    for (int p0 = 0; p0 < NP; p0 += UB) {
+        for (int j0 = 0; j0 < RP; j0 += 64) {
+            const int j = j0 + lane, jr = j - (G - 1);
+            unsigned char raw[UB]; bool ok[UB];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int item = item0 + u * 64 + lane;
-            const int p = min(item / RP, NP - 1), j = item - p * RP;
-            const int jj = j - (G - 1);
-            ok[u] = item < NP * RP && jj >= 0 && jj < (int)ptab[5 * p + 3];
-            pad[u] = (NP - p) * msize;
-            raw[u] = ok[u] ? rbase[ptab[5 * p + 2] + jj] : (unsigned char)0;
-        }
+            for (int u = 0; u < UB; ++u) {
+                const int p = p0 + u;
+                ok[u] = jr >= 0 && jr < (int)ptab[5 * p + 3];
+                raw[u] = ok[u] ? rbase[ptab[5 * p + 2] + jr] : (unsigned char)0;
+            }
+            if (j < RP) {
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int item = item0 + u * 64 + lane;
-            if (item < NP * RP) rsym[item] = ok[u] ? map[raw[u]] : (unsigned char)pad[u];
+                for (int u = 0; u < UB; ++u) {
+                    const int p = p0 + u;
+                    rsym[p * RP + j] = ok[u] ? map[raw[u]] : (unsigned char)((NP - p) * msize);
+                }
+            }
         }
     }
 
