@@ -155,7 +155,7 @@ def main():
     d_out = [torch.zeros((n, 4), dtype=torch.int32, device=dev) for _ in range(2)]
     matrix = pkg.Matrix.create(b"ACGT", MATCH, MISMATCH)
     cfg = pkg.pmx_config_t(pkg.MODE_SW, 0, OPEN, EXT, 16, 0, matrix.inner)
-    kernel = pkg.lib.pmx_kernel_for(C.byref(cfg), LEN, LEN).decode() + "<8,19>/max3+vop2+u8+skew"
+    kernel = pkg.lib.pmx_kernel_for(C.byref(cfg), LEN, LEN).decode() + "<8,19>/max3+vop2+skew+permtable"
 
     from importlib import import_module
     sharding = import_module("parasail_rs_amd.sharding")

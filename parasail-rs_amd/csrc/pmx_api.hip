@@ -956,7 +956,7 @@ extern "C" const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen,
 
 // grow-only per-(thread,device) scratch for the general kernel's band boundary rows
 struct Scratch { void *p = nullptr; size_t cap = 0; int dev = -1; };
-enum { SCR_BOUND = 0, SCR_TRACE = 1, SCR_OPS = 2, SCR_SORT = 3, SCR_SLOTS = 4 };
+enum { SCR_BOUND = 0, SCR_TRACE = 1, SCR_OPS = 2, SCR_SORT = 3, SCR_RETRY = 4, SCR_SLOTS = 5 };
 static thread_local Scratch g_scratch_pool[SCR_SLOTS];
 static int scratch_reserve(size_t bytes, void **out, int slot = SCR_BOUND)
 {
@@ -987,7 +987,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
     DevMat dm;
     if (get_devmat(cfg->matrix, &dm)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, max_qlen, max_rlen, q_shared, nullptr};
+    PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, max_qlen, max_rlen, q_shared, nullptr, nullptr, nullptr, 0};
     const int want = cfg->want & ~PMX_WANT_SORTED;
     if ((cfg->want & PMX_WANT_SORTED) && n >= 64 && n < (1LL << 32)) {
         void *scr = nullptr;
@@ -996,6 +996,13 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         if (rc < 0) { set_err("length sort failed (%d)", rc); return rc; }
     }
     if (fast_sw_eligible(cfg)) {
+        if (!q_shared && n >= 4096 && n < (1LL << 32)) {
+            // scratch that lets the launcher pick a kernel which hands some pairs back for a second launch
+            void *scr = nullptr;
+            if (scratch_reserve(((size_t)n + 1) * sizeof(unsigned), &scr, SCR_RETRY)) return -1;
+            b.retry_count = (int *)scr;
+            b.retry_list = (unsigned *)scr + 1;
+        }
         const int rc = pmx_launch_sw16(b, dm.d, cfg->open, cfg->extend, d_out, st, nullptr);
         if (rc < 0) { set_err("sw16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
         if (rc == 0) {
@@ -1191,7 +1198,7 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
     HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(doo.p, ops_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
 
-    PmxBatch b = {dq.p, dqo.p, dr.p, dro.p, n, mq, mr, 0, nullptr};
+    PmxBatch b = {dq.p, dqo.p, dr.p, dro.p, n, mq, mr, 0, nullptr, nullptr, nullptr, 0};
     int variant = 0, Tmax = 0; size_t tbytes = 0;
     int rc;
     if (cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&

@@ -25,7 +25,11 @@ struct PmxBatch {
     int max_qlen, max_rlen;
     int q_shared;            // > 0: one shared query of that many bytes at qbuf (profile arm), qoff unused
     const unsigned *perm;    // optional processing order (pmx_sort.hip): position -> pair index
+    unsigned *retry_list;    // optional scratch, n entries + one int: lets the sw16 launcher use kernels that hand
+    int *retry_count;        //   some pairs back for a second launch (decided on the device, no host sync)
+    int q_has_wildcard;      // shared query only: it holds a letter beyond the first four of the alphabet
 };
+#define PMX_FLAG_RETRY16 4   // internal record flag: redo with the LDS-profile variant of the fast kernel
 
 // Fast path: local alignment, score + end positions, packed int16 lanes.
 // Returns 0 if launched, 1 if the shape is not supported by any instantiation (caller falls

@@ -79,7 +79,7 @@ __device__ __forceinline__ v2s pk_max3f(v2s a, v2s b, v2s c)   // integer max3 o
 #define FLOOR2 0x80008000   // both halves = -32768 = "zero" of the offset domain
 
 template <int G, int R, int VAR>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64, VAR == 6 ? 4 : 1)
 void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                      const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
                      long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
@@ -87,11 +87,19 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                      int q_shared /* > 0: every pair uses qbuf[0..q_shared) */,
                      int limit /* M3 only: biased scores at or above this are flagged for a re-run (SK: growth already taken off) */,
                      const unsigned *__restrict__ perm,
+                     const int *__restrict__ n_dev /* != nullptr: the pair count is read from the device (retry launches) */,
+                     unsigned *__restrict__ retry_list, int *__restrict__ retry_count /* PT: pairs to redo */,
                      pmx_record_t *__restrict__ out)
 {
+    if (n_dev) n = *n_dev;
+    if ((long long)blockIdx.x * (2 * (64 / G)) >= n) return;
     constexpr bool M3 = VAR >= 1;      // biased unsigned lanes, v_pk_maximum3_f16 as integer max3
     constexpr bool V2 = VAR >= 2;      // + full-rate 32-bit VOP2 add/sub on packed lanes (no cross-half carry)
-    constexpr bool U8 = VAR == 3 || VAR == 5;   // + one-byte profile entries (score + open fits 0..255): half the LDS, same v_perm count
+    constexpr bool PT = VAR == 6;      // + no LDS profile at all: alphabets of <= 4 letters (+ wildcard) look the score up with the
+                                       //   v_perm itself -- table = the 4 scores of this step's reference symbol (one dword per pair),
+                                       //   selector = the lane's query letters (one VGPR per row).  Query wildcards cannot be
+                                       //   expressed: such pairs are flagged PMX_FLAG_RETRY16 and redone with the LDS profile.
+    constexpr bool U8 = VAR == 3 || VAR == 5 || PT;   // + one-byte profile entries (score + open fits 0..255): half the LDS, same v_perm count
     constexpr bool SK = VAR >= 4;      // + column-skewed values (everything in column j carries +(j+G)*ext): E needs no subtract
     constexpr int EB = U8 ? 1 : 2;     // bytes per profile entry
     constexpr int WR = U8 ? 4 : 2;     // rows per loaded dword
@@ -105,16 +113,18 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     const int lane = threadIdx.x;
     const int g = lane % G;
     const int slot = lane / G;
-    const int PROF_STRIDE = msize * QP * EB;   // bytes per pair
+    const int PROF_STRIDE = PT ? 0 : msize * QP * EB;   // bytes per pair
 
     // LDS carve: [prof NP][shared pad row QP*2][rsym NP*RP][mat msize*msize*2][map 256][pair table NP*4 ints]
     // The pad row sits right behind the last pair's profile; pair p reaches it with the symbol
     // value (NP - p) * msize, so no per-pair copy is needed.
     int16_t *prof = reinterpret_cast<int16_t *>(lds);
-    unsigned char *rsym = lds + NP * PROF_STRIDE + QP * EB;
+    unsigned char *rsym = lds + (PT ? 0 : NP * PROF_STRIDE + QP * EB);
     int16_t *mat = reinterpret_cast<int16_t *>(rsym + NP * RP);
     unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
     long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));   // per pair: q offset, qlen, r offset, rlen, pair index
+
+    int *tabs = reinterpret_cast<int *>(ptab + 5 * NP);      // PT: per reference symbol the 4 query-letter scores (+open), entry msize = pad = 0
 
     const long long pair0 = (long long)blockIdx.x * NP;
 
@@ -157,15 +167,15 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
                     const int p = p0 + u;
-                    rsym[p * RP + j] = ok[u] ? map[raw[u]] : (unsigned char)((NP - p) * msize);
+                    rsym[p * RP + j] = ok[u] ? map[raw[u]] : (unsigned char)(PT ? msize : (NP - p) * msize);
                 }
             }
         }
     }
 
     // ---- query profiles: one (pair, row pair) item per lane and iteration -----------------
-    constexpr int QITEMS = (NP * QP2 + 63) / 64;          // items per lane (compile time)
-    constexpr int QB = QITEMS < 5 ? QITEMS : 5;
+    constexpr int QITEMS = PT ? 0 : (NP * QP2 + 63) / 64;          // items per lane (compile time)
+    constexpr int QB = QITEMS < 5 ? (QITEMS < 1 ? 1 : QITEMS) : 5;
     for (int it0 = 0; it0 < QITEMS; it0 += QB) {
         unsigned char r0[QB], r1[QB]; bool v0[QB], v1[QB];
 #pragma unroll
@@ -203,8 +213,38 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
             }
         }
     }
-    for (int idx = lane; idx < QP * EB / 4; idx += 64)
-        reinterpret_cast<int *>(lds + NP * PROF_STRIDE)[idx] = V2 ? 0 : FLOOR2;
+    if (!PT) {
+        for (int idx = lane; idx < QP * EB / 4; idx += 64)
+            reinterpret_cast<int *>(lds + NP * PROF_STRIDE)[idx] = V2 ? 0 : FLOOR2;
+    }
+    // PT: score tables and the per-row selectors (byte 0: pair A's letter 0..3 -> table A = v_perm source bytes 0..3,
+    // byte 2: 4 + pair B's letter -> table B = bytes 4..7, bytes 1 and 3: 0x0C = constant 0; padding rows and wildcard
+    // rows select the constant 0, i.e. score -open: harmless below the query, wrong for a wildcard -> the pair is flagged)
+    int sel[R];
+    int wild = 0;
+    if (PT) {
+        if (lane <= msize) {
+            int v = 0;
+            if (lane < msize)
+                for (int k = 0; k < 4 && k < msize; ++k) v |= ((mat[k * msize + lane] + open) & 0xFF) << (8 * k);
+            tabs[lane] = v;
+        }
+        const int rowbase = g * R;
+        const int qlA = (int)ptab[5 * (2 * slot) + 1], qlB = (int)ptab[5 * (2 * slot + 1) + 1];
+        const uint8_t *qA = qbase + ptab[5 * (2 * slot) + 0] + rowbase, *qB = qbase + ptab[5 * (2 * slot + 1) + 0] + rowbase;
+        unsigned char ra[R], rb[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            ra[k] = rowbase + k < qlA ? qA[k] : (unsigned char)0;
+            rb[k] = rowbase + k < qlB ? qB[k] : (unsigned char)0;
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int ca = rowbase + k < qlA ? map[ra[k]] : -1, cb = rowbase + k < qlB ? map[rb[k]] : -1;
+            wild |= (ca >= 4 ? 1 : 0) | (cb >= 4 ? 2 : 0);
+            sel[k] = ((ca >= 0 && ca < 4) ? ca : 0x0C) | 0x0C00 | (((cb >= 0 && cb < 4) ? 4 + cb : 0x0C) << 16) | 0x0C000000;
+        }
+    }
     __syncthreads();
 
     // ---- systolic sweep ---------------------------------------------------------------
@@ -248,6 +288,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     v2s diag0 = PK(SK ? I32(vInitH) : HNEUTRAL);   // H(i0-1, j-1)   (V2: minus open)
 
     auto load_scores = [&](int symA, int symB, int (&wa)[RS / WR], int (&wb)[RS / WR]) {
+        if (PT) { wa[0] = tabs[symA]; wb[0] = tabs[symB]; return; }
         const int *sa = reinterpret_cast<const int *>(profA + symA * SYMSTRIDE);
         const int *sb = reinterpret_cast<const int *>(profB + symB * SYMSTRIDE);
 #pragma unroll
@@ -262,7 +303,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         if (V2) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const v2s s = U8 ? PK(__builtin_amdgcn_perm(wb[k / 4], wa[k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16)))
+                const v2s s = PT ? PK(__builtin_amdgcn_perm(wb[0], wa[0], (unsigned)sel[k]))
+                            : U8 ? PK(__builtin_amdgcn_perm(wb[k / 4], wa[k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16)))
                                : PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
                 const v2s d = (k == 0) ? diag0 : Hold[k - 1];
                 Tpre[k] = PK(I32(d) + I32(s));
@@ -272,7 +314,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const v2s s = U8 ? PK(__builtin_amdgcn_perm(wb[k / 4], wa[k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16)))
+            const v2s s = PT ? PK(__builtin_amdgcn_perm(wb[0], wa[0], (unsigned)sel[k]))
+                        : U8 ? PK(__builtin_amdgcn_perm(wb[k / 4], wa[k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16)))
                                : PK(__builtin_amdgcn_perm(wb[k / 2], wa[k / 2], (k & 1) ? 0x07060302 : 0x05040100));
             const v2s d = (k == 0) ? diag0 : Hold[k - 1];
             v2s H;
@@ -388,6 +431,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         const unsigned long long oa = __shfl_xor(keyA, off, 64), ob = __shfl_xor(keyB, off, 64);
         keyA = oa > keyA ? oa : keyA;
         keyB = ob > keyB ? ob : keyB;
+        if (PT) wild |= __shfl_xor(wild, off, 64);
     }
     if (g == 0) {
 #pragma unroll
@@ -401,6 +445,10 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 rec.end_query = 0xFFFF - (int)(key & 0xFFFF);
                 if (M3) rec.flags = (rec.score + M3_BIAS >= limit) ? PMX_FLAG_RERUN : 0;   // left the exact range: redo in 32 bits
                 else rec.flags = rec.score > 32767 ? PMX_FLAG_SATURATED : 0;
+                if (PT && ((wild >> h) & 1)) {                                              // wildcard in the query: redo with the LDS profile
+                    rec.flags = PMX_FLAG_RETRY16;
+                    retry_list[atomicAdd(retry_count, 1)] = (unsigned)pi;
+                }
                 out[pi] = rec;
             }
         }
@@ -411,23 +459,37 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 
 template <int G, int R, int VAR>
 static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
-                      pmx_record_t *d_out, hipStream_t stream)
+                      pmx_record_t *d_out, hipStream_t stream, const int *n_dev = nullptr)
 {
-    constexpr int EB = (VAR == 3 || VAR == 5) ? 1 : 2, WR = 4 / EB, RS = (R + WR - 1) / WR * WR;
+    constexpr bool PT = VAR == 6;
+    constexpr int EB = (VAR == 3 || VAR == 5 || PT) ? 1 : 2, WR = 4 / EB, RS = (R + WR - 1) / WR * WR;
     constexpr int QP = G * RS, NP = 2 * (64 / G);
     if (NP * m.msize > 255) return 1;                 // per-pair pad symbol must fit a byte
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
-    const size_t lds = (size_t)NP * m.msize * QP * EB + (size_t)QP * EB + (size_t)NP * RP +
-                       (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
+    const size_t lds = (PT ? 0 : (size_t)NP * m.msize * QP * EB + (size_t)QP * EB) + (size_t)NP * RP +
+                       (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40 + 32;
     if (lds > 160 * 1024) return 1;
     { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_sw16_kernel<G, R, VAR>)); if (rc) return rc; }
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
+    if (PT) {
+        hipError_t e = hipMemsetAsync(b.retry_count, 0, sizeof(int), stream);
+        if (e != hipSuccess) return -(int)e;
+    }
     hipLaunchKernelGGL((pmx_sw16_kernel<G, R, VAR>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
-                       m.msize, open, ext, RP, b.q_shared, M3_LIMIT(m.max) - (VAR >= 4 ? (b.max_rlen + 2 * G + 4) * ext : 0), b.perm, d_out);
+                       m.msize, open, ext, RP, b.q_shared, M3_LIMIT(m.max) - (VAR >= 4 ? (b.max_rlen + 2 * G + 4) * ext : 0), b.perm,
+                       n_dev, b.retry_list, b.retry_count, d_out);
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : -(int)e;
+    if (e != hipSuccess) return -(int)e;
+    if (PT) {
+        // Pairs with a wildcard in the query: same shape, LDS-profile variant, driven by the device-side
+        // count (no host synchronisation; blocks beyond the count leave at once).
+        PmxBatch r = b;
+        r.perm = b.retry_list;
+        return launch_one<G, R, 5>(r, m, open, ext, d_out, stream, b.retry_count);
+    }
+    return 0;
 }
 
 int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
@@ -465,10 +527,13 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
     }
     // byte profile, 8 lanes per pair: half the fill/drain and per-step overhead of <16,10> at the same LDS;
     // rows per lane chosen for the common read lengths (100, 125, 150) so that few rows are padding
+    // alphabets of <= 4 letters (+ wildcard): no LDS profile, the v_perm looks the score up (see PT in the kernel)
+    const bool pt = sk && u8ok && m.msize <= 5 && b.retry_list && b.retry_count && !b.q_has_wildcard && !getenv("PMX_SW16_NO_PERMTABLE");
 #define TRY8(RR)                                                                \
     if (u8ok && q <= 8 * (RR)) {                                                \
-        int rc = sk ? launch_one<8, RR, 5>(b, m, open, ext, d_out, stream) : launch_one<8, RR, 3>(b, m, open, ext, d_out, stream); \
-        if (rc <= 0) { if (kernel_name) *kernel_name = sk ? "pmx_sw16_kernel<8," #RR ">/max3+vop2+u8+skew" : "pmx_sw16_kernel<8," #RR ">/max3+vop2+u8"; return rc; } \
+        int rc = pt ? launch_one<8, RR, 6>(b, m, open, ext, d_out, stream)      \
+               : sk ? launch_one<8, RR, 5>(b, m, open, ext, d_out, stream) : launch_one<8, RR, 3>(b, m, open, ext, d_out, stream); \
+        if (rc <= 0) { if (kernel_name) *kernel_name = pt ? "pmx_sw16_kernel<8," #RR ">/max3+vop2+skew+permtable" : sk ? "pmx_sw16_kernel<8," #RR ">/max3+vop2+u8+skew" : "pmx_sw16_kernel<8," #RR ">/max3+vop2+u8"; return rc; } \
     }
     TRY8(13) TRY8(16) TRY8(19) TRY8(20)
 #undef TRY8

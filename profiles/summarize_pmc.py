@@ -1,0 +1,22 @@
+"""Summarise rocprofv3 PMC csv output: mean per launch of every counter for kernels matching a name.
+usage: python profiles/summarize_pmc.py <dir with *counter_collection.csv> <kernel substring> <out.json>"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+
+def main(root, needle, out):
+    acc = defaultdict(lambda: defaultdict(float))       # counter -> dispatch id -> sum over dimensions
+    for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if needle not in row["Kernel_Name"]:
+                    continue
+                acc[row["Counter_Name"]][(path, row["Dispatch_Id"])] += float(row["Counter_Value"])
+    res = {c: {"launches": len(d), "mean_per_launch": sum(d.values()) / len(d)} for c, d in acc.items()}
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps({c: round(v["mean_per_launch"]) for c, v in res.items()}))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])

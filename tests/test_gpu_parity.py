@@ -217,7 +217,7 @@ def test_sw16_file_matrix_asymmetric(pkg, orc):
     _fast_case(pkg, orc, qs, rs, 5, 2, pm, om)
 
 
-@pytest.mark.parametrize("env", [{}, {"PMX_SW16_NO_SKEW": "1"}, {"PMX_SW16_NO_U8": "1"},
+@pytest.mark.parametrize("env", [{}, {"PMX_SW16_NO_PERMTABLE": "1"}, {"PMX_SW16_NO_SKEW": "1"}, {"PMX_SW16_NO_U8": "1"},
                                  {"PMX_SW16_NO_U8": "1", "PMX_SW16_NO_SKEW": "1"},
                                  {"PMX_SW16_VARIANT": "1"}, {"PMX_SW16_VARIANT": "0"}])
 def test_sw16_every_arithmetic_variant(pkg, orc, monkeypatch, env):
@@ -243,6 +243,28 @@ def test_sw16_every_arithmetic_variant(pkg, orc, monkeypatch, env):
     qs = random_seqs(rng, 100, 30, 256, AA)
     rs = [mutate(rng, q, 0.3, 0.05, AA) for q in qs]
     _fast_case(pkg, orc, qs, rs, 11, 1, bm, bo)
+
+
+@pytest.mark.parametrize("qmax", [100, 128, 150, 160])
+def test_sw16_permtable_variant_and_wildcard_retry(pkg, orc, qmax):
+    """batches of >= 4096 short DNA pairs take the perm-table kernel; pairs with a wildcard in the query are
+    handed back on the device and redone with the LDS profile (no flag may leak out)"""
+    rng = np.random.default_rng(1470 + qmax)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    n = 6000
+    qs = random_seqs(rng, n, qmax // 2, qmax)
+    qs[0] = random_seqs(rng, 1, qmax, qmax)[0]
+    rs = [mutate(rng, q, 0.08, 0.04) if rng.random() < 0.7 else random_seqs(rng, 1, 1, 220)[0] for q in qs]
+    for i in range(0, n, 37):                                         # wildcards in queries -> retry path
+        q = bytearray(qs[i]); q[int(rng.integers(len(q)))] = ord("N"); qs[i] = bytes(q)
+    for i in range(5, n, 41):                                         # wildcards in references: handled in place
+        r = bytearray(rs[i]); r[int(rng.integers(len(r)))] = ord("N"); rs[i] = bytes(r)
+    qs[1] = b"N" * 10; rs[1] = b"N" * 10
+    qs[2] = qs[2].lower()
+    _fast_case(pkg, orc, qs, rs, 5, 2, pm, om)
+    _fast_case(pkg, orc, qs, rs, 3, 3, pm, om, width=0)
+    same = [random_seqs(rng, 1, qmax, qmax)[0]] * 4100                # uniform lengths: no sort, all blocks full but the last
+    _fast_case(pkg, orc, same, same, 5, 2, pm, om)
 
 
 def test_sw16_saturating_int16_variant(pkg, orc):
