@@ -125,6 +125,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));   // per pair: q offset, qlen, r offset, rlen, pair index
 
     int *tabs = reinterpret_cast<int *>(ptab + 5 * NP);      // PT: per reference symbol the 4 query-letter scores (+open), entry msize = pad = 0
+    constexpr int QS = (G * R + 3) / 4 * 4;
+    unsigned char *qsym = reinterpret_cast<unsigned char *>(tabs + 8);   // PT: mapped query letters, QS bytes per pair (0xFF below the query)
 
     const long long pair0 = (long long)blockIdx.x * NP;
 
@@ -168,6 +170,25 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 for (int u = 0; u < UB; ++u) {
                     const int p = p0 + u;
                     rsym[p * RP + j] = ok[u] ? map[raw[u]] : (unsigned char)(PT ? msize : (NP - p) * msize);
+                }
+            }
+        }
+    }
+
+    if (PT) {          // query letters, staged the same way (coalesced loads; the lanes pick their rows up from LDS)
+        for (int p0 = 0; p0 < NP; p0 += UB) {
+            for (int j0 = 0; j0 < QS; j0 += 64) {
+                const int j = j0 + lane;
+                unsigned char raw[UB]; bool ok[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int p = p0 + u;
+                    ok[u] = j < (int)ptab[5 * p + 1];
+                    raw[u] = ok[u] ? qbase[ptab[5 * p + 0] + j] : (unsigned char)0;
+                }
+                if (j < QS) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) qsym[(p0 + u) * QS + j] = ok[u] ? map[raw[u]] : (unsigned char)0xFF;
                 }
             }
         }
@@ -229,21 +250,17 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 for (int k = 0; k < 4 && k < msize; ++k) v |= ((mat[k * msize + lane] + open) & 0xFF) << (8 * k);
             tabs[lane] = v;
         }
-        const int rowbase = g * R;
-        const int qlA = (int)ptab[5 * (2 * slot) + 1], qlB = (int)ptab[5 * (2 * slot + 1) + 1];
-        const uint8_t *qA = qbase + ptab[5 * (2 * slot) + 0] + rowbase, *qB = qbase + ptab[5 * (2 * slot + 1) + 0] + rowbase;
-        unsigned char ra[R], rb[R];
+    }
+    __syncthreads();
+    if (PT) {
+        const unsigned char *qa = qsym + (2 * slot) * QS + g * R, *qb = qa + QS;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            ra[k] = rowbase + k < qlA ? qA[k] : (unsigned char)0;
-            rb[k] = rowbase + k < qlB ? qB[k] : (unsigned char)0;
+            const int ca = qa[k], cb = qb[k];          // 0..3 letter, 4.. wildcard, 0xFF below the query
+            wild |= ((ca >= 4 && ca != 0xFF) ? 1 : 0) | ((cb >= 4 && cb != 0xFF) ? 2 : 0);
+            sel[k] = (ca < 4 ? ca : 0x0C) | 0x0C00 | ((cb < 4 ? 4 + cb : 0x0C) << 16) | 0x0C000000;
         }
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int ca = rowbase + k < qlA ? map[ra[k]] : -1, cb = rowbase + k < qlB ? map[rb[k]] : -1;
-            wild |= (ca >= 4 ? 1 : 0) | (cb >= 4 ? 2 : 0);
-            sel[k] = ((ca >= 0 && ca < 4) ? ca : 0x0C) | 0x0C00 | (((cb >= 0 && cb < 4) ? 4 + cb : 0x0C) << 16) | 0x0C000000;
-        }
+        asm volatile("" : "+v"(wild));     // computed here: otherwise the compiler sinks it behind the sweep and spills the letters
     }
     __syncthreads();
 
@@ -466,7 +483,7 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
     constexpr int QP = G * RS, NP = 2 * (64 / G);
     if (NP * m.msize > 255) return 1;                 // per-pair pad symbol must fit a byte
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
-    const size_t lds = (PT ? 0 : (size_t)NP * m.msize * QP * EB + (size_t)QP * EB) + (size_t)NP * RP +
+    const size_t lds = (PT ? (size_t)NP * ((G * R + 3) / 4 * 4) : (size_t)NP * m.msize * QP * EB + (size_t)QP * EB) + (size_t)NP * RP +
                        (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40 + 32;
     if (lds > 160 * 1024) return 1;
     { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_sw16_kernel<G, R, VAR>)); if (rc) return rc; }
