@@ -32,9 +32,9 @@ HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8.0 T
 # VALU ceiling for the hot kernel (DESIGN.md "Roofline").  Measured issue rates on this chip
 # (profiles/r01/valu_rate_microbench.txt): a VOP3/VOP3P wave64 instruction (v_pk_maximum3_f16,
 # v_perm_b32, v_bfi_b32) takes 4 cycles of its SIMD, a 32-bit-encoded VOP2 (v_add_u32, v_sub_u32)
-# 2 cycles.  Per 2 cells x 64 lanes the max3+vop2 variant issues 5.5 VOP3 + 4 VOP2 = 30 cycles.
+# 2 cycles.  Per 2 cells x 64 lanes the skewed max3+vop2 variant issues 5.5 VOP3 + 3 VOP2 = 28 cycles.
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
-CYCLES_PER_128_CELLS = 5.5 * 4 + 4 * 2
+CYCLES_PER_128_CELLS = 5.5 * 4 + 3 * 2
 
 
 def make_cfg2_inputs(n=N_PAIRS, seed=SEED):
@@ -155,7 +155,6 @@ def main():
     d_out = [torch.zeros((n, 4), dtype=torch.int32, device=dev) for _ in range(2)]
     matrix = pkg.Matrix.create(b"ACGT", MATCH, MISMATCH)
     cfg = pkg.pmx_config_t(pkg.MODE_SW, 0, OPEN, EXT, 16, 0, matrix.inner)
-    kernel = pkg.lib.pmx_kernel_for(C.byref(cfg), LEN, LEN).decode() + "<8,19>/max3+vop2+skew+permtable"
 
     from importlib import import_module
     sharding = import_module("parasail_rs_amd.sharding")
@@ -214,6 +213,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if evs else float("nan")
+    kernel = pkg.lib.pmx_last_kernel().decode()        # name + shape + arithmetic variant of what this thread just launched
 
     cells_per_rank_step = n * LEN * LEN
     total_cells = cells_per_rank_step * world * args.steps
@@ -239,7 +239,7 @@ def main():
                          "note": "312 algorithmic B/pair; the path is VALU-bound, see roofline_valu"},
             "roofline_valu": {"bound": "valu", "achieved": round(kern_gcups, 2), "peak": round(valu_peak_gcups, 1),
                               "unit": "GCUPS", "frac": round(kern_gcups / valu_peak_gcups, 4),
-                              "model": "per 128 cells: 5.5 VOP3/VOP3P x 4 cycles + 4 VOP2 x 2 cycles = 30 SIMD cycles; "
+                              "model": "per 128 cells: 5.5 VOP3/VOP3P x 4 cycles + 3 VOP2 x 2 cycles = 28 SIMD cycles; "
                                        "1024 SIMDs x 2.4 GHz (measured issue rates, profiles/r01)"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -294,6 +294,8 @@ const char *pmx_last_error(void);
 const char *pmx_version(void);
 /* Name of the kernel family the dispatcher would use for a config and size (diagnostics). */
 const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen, int32_t max_rlen);
+/* Name (with template shape and arithmetic variant) of the kernel the calling thread's last batch call launched. */
+const char *pmx_last_kernel(void);
 
 #ifdef __cplusplus
 }

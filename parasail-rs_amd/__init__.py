@@ -113,6 +113,7 @@ _sig("pmx_version", C.c_char_p)
 _sig("pmx_device_count", C.c_int)
 _sig("pmx_set_device", C.c_int, C.c_int)
 _sig("pmx_kernel_for", C.c_char_p, C.POINTER(pmx_config_t), C.c_int32, C.c_int32)
+_sig("pmx_last_kernel", C.c_char_p)
 _sig("pmx_align_batch", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
      C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("pmx_align_batch_device", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

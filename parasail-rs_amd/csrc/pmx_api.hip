@@ -972,6 +972,9 @@ static int scratch_reserve(size_t bytes, void **out, int slot = SCR_BOUND)
     return 0;
 }
 
+static thread_local const char *g_last_kernel = "";
+extern "C" const char *pmx_last_kernel(void) { return g_last_kernel; }
+
 // Device-resident batch.  q_shared > 0: every pair uses the one query d_qbuf[0..q_shared) (profile arm).
 static int run_batch_device(const pmx_config_t *cfg, int64_t n,
                             const uint8_t *d_qbuf, const int64_t *d_qoff, int q_shared,
@@ -1003,7 +1006,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
             b.retry_count = (int *)scr;
             b.retry_list = (unsigned *)scr + 1;
         }
-        const int rc = pmx_launch_sw16(b, dm.d, cfg->open, cfg->extend, d_out, st, nullptr);
+        const int rc = pmx_launch_sw16(b, dm.d, cfg->open, cfg->extend, d_out, st, &g_last_kernel);
         if (rc < 0) { set_err("sw16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
         if (rc == 0) {
             // Overflow promotion (`sat`, 32, 64): pairs whose int16 lanes overflowed are re-run in the
@@ -1039,13 +1042,13 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         // rc == 1: shape not covered by the fast kernel -> general kernel below
     }
     if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
-        const int rc = pmx_launch_stats16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, d_stats_out, st, nullptr);
+        const int rc = pmx_launch_stats16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, d_stats_out, st, &g_last_kernel);
         if (rc < 0) { set_err("stats16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
         if (rc == 0) return 0;
     }
     if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && want == 0 && cfg->width != 8 &&
         cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
-        const int rc = pmx_launch_nwsg16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, st, nullptr);
+        const int rc = pmx_launch_nwsg16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, st, &g_last_kernel);
         if (rc < 0) { set_err("nwsg16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
         if (rc == 0) return 0;     // the host-side range proof makes overflow impossible: no promotion pass
     }
@@ -1063,6 +1066,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
     a.rec = d_out; a.stats = d_stats_out;
     const int rc = pmx_launch_general(a, (want & PMX_WANT_STATS) != 0, st);
     if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    g_last_kernel = "pmx_general_kernel";
     return 0;
 }
 
