@@ -51,6 +51,13 @@ __device__ __forceinline__ v2s n_max3(v2s a, v2s b, v2s c)
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(I32(a)), "v"(I32(b)), "v"(I32(c)));
     return PK(r);
 }
+typedef _Float16 n_v2h __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s n_max3f(v2s a, v2s b, v2s c)     // same instruction, as a builtin (no inline-asm wait states)
+{
+    const n_v2h r = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(n_v2h, a), __builtin_bit_cast(n_v2h, b)),
+                                                  __builtin_bit_cast(n_v2h, c));
+    return __builtin_bit_cast(v2s, r);
+}
 __device__ __forceinline__ int n_bfi(int m, int a, int b)
 {
     int r;
@@ -355,6 +362,284 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Second generation (same mapping, same results): the arithmetic of pmx_sw16.hip's fastest variant.
+//   * column-skewed values: a value of column j is kept as value + nb + (j + G) * ext, so
+//     E(j+1) = max(E(j) - ext, H(j) - open) needs no subtract; F keeps one more +ext so that the single
+//     X = H - (open - ext) serves E, F and the strip (the next column's diagonal source);
+//   * the profile carries score + open (one byte, >= 0), so add and subtract never carry or borrow
+//     between the int16 halves and run as 32-bit VOP2;
+//   * no "-inf": a penalised virtual row / column scores -open (profile byte 0), which can never beat
+//     the E / F chain that carries -(open + k ext) there (open >= ext); the row above lane 0 is the
+//     closed form of that chain (a constant in the skewed domain) or, for a free reference begin, 0;
+//   * the bias nb is chosen by the host from the proven value range (room for the skew growth).
+template <int G, int R>
+__global__ __launch_bounds__(64)
+void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
+                        const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
+                        long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
+                        int msize, int open, int ext, int RP, int q_shared,
+                        int col_pen, int row_pen, int s1_end, int s2_end, int nb,
+                        const unsigned *__restrict__ perm,
+                        pmx_record_t *__restrict__ out)
+{
+    constexpr int RS = (R + 3) / 4 * 4;      // profile bytes reserved per lane (whole dwords)
+    constexpr int QP = G * R;                // logical rows (query bottom-aligned in them)
+    constexpr int QPS = G * RS;              // profile bytes per (pair, symbol)
+    constexpr int SLOTS = 64 / G;
+    constexpr int NP = 2 * SLOTS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int lane = threadIdx.x;
+    const int g = lane % G;
+    const int slot = lane / G;
+    const int MS1 = msize + 1;                      // + the pad-symbol row
+    const int PROF_STRIDE = MS1 * QPS;
+
+    unsigned char *rsym = lds + NP * PROF_STRIDE;
+    int16_t *mat = reinterpret_cast<int16_t *>(rsym + NP * RP);
+    unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
+    long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));
+
+    const long long pair0 = (long long)blockIdx.x * NP;
+    for (int i = lane; i < msize * msize; i += 64) mat[i] = gmat[i];
+    for (int i = lane; i < 256; i += 64) map[i] = gmap[i];
+    if (lane < NP) {
+        long long pos = pair0 + lane; if (pos >= n) pos = n - 1;
+        const long long pi = perm ? (long long)perm[pos] : pos;
+        const long long qb = q_shared ? 0 : qoff[pi], rb = roff[pi];
+        ptab[5 * lane + 0] = qb;
+        ptab[5 * lane + 1] = q_shared ? q_shared : (qoff[pi + 1] - qb);
+        ptab[5 * lane + 2] = rb;
+        ptab[5 * lane + 3] = roff[pi + 1] - rb;
+        ptab[5 * lane + 4] = (pair0 + lane < n) ? pi : -1;
+    }
+    __syncthreads();
+
+    // ---- reference symbols (pairs in batches of UB, lanes over positions: no division, UB loads in flight)
+    int max_rlen = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) max_rlen = max(max_rlen, (int)ptab[5 * p + 3]);
+    constexpr int UB = NP < 8 ? NP : 8;
+    for (int p0 = 0; p0 < NP; p0 += UB) {
+        for (int j0 = 0; j0 < RP; j0 += 64) {
+            const int j = j0 + lane, jr = j - (G - 1);
+            unsigned char raw[UB]; bool ok[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int p = p0 + u;
+                ok[u] = jr >= 0 && jr < (int)ptab[5 * p + 3];
+                raw[u] = ok[u] ? rbuf[ptab[5 * p + 2] + jr] : (unsigned char)0;
+            }
+            if (j < RP) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) rsym[(p0 + u) * RP + j] = ok[u] ? map[raw[u]] : (unsigned char)msize;
+            }
+        }
+    }
+
+    // ---- byte profiles: logical row er = l * R + k sits at byte l * RS + k; P virtual rows on top
+    const int vrow_b = row_pen ? 0 : open;         // virtual row x real symbol
+    const int vcol_b = col_pen ? 0 : open;         // real row    x pad symbol
+    for (int p0 = 0; p0 < NP; p0 += UB) {
+        for (int e0 = 0; e0 < QP; e0 += 64) {
+            const int er = e0 + lane;
+            unsigned char raw[UB]; bool real[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int p = p0 + u;
+                const int P = QP - (int)ptab[5 * p + 1];
+                real[u] = er < QP && er >= P;
+                raw[u] = real[u] ? qbuf[ptab[5 * p + 0] + er - P] : (unsigned char)0;
+            }
+            if (er < QP) {
+                const int pos = (er / R) * RS + er % R;
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    unsigned char *pp = lds + (p0 + u) * PROF_STRIDE + pos;
+                    if (real[u]) {
+                        const int q = map[raw[u]];
+                        for (int sym = 0; sym < msize; ++sym) pp[sym * QPS] = (unsigned char)(mat[q * msize + sym] + open);
+                        pp[msize * QPS] = (unsigned char)vcol_b;
+                    } else {
+                        for (int sym = 0; sym < msize; ++sym) pp[sym * QPS] = (unsigned char)vrow_b;
+                        pp[msize * QPS] = (unsigned char)open;          // virtual x virtual: score 0
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane state ------------------------------------------------------------------
+    const int pA = 2 * slot, pB = 2 * slot + 1;
+    const unsigned char *profA = lds + pA * PROF_STRIDE + g * RS;
+    const unsigned char *profB = lds + pB * PROF_STRIDE + g * RS;
+    const unsigned char *rsA = rsym + pA * RP + (G - 1) - g;
+    const unsigned char *rsB = rsym + pB * RP + (G - 1) - g;
+
+    const int PvA = QP - (int)ptab[5 * pA + 1], PvB = QP - (int)ptab[5 * pB + 1];
+    const int rlA = (int)ptab[5 * pA + 3], rlB = (int)ptab[5 * pB + 3];
+    auto pack2 = [](int a, int b) -> int { return (a & 0xFFFF) | (b << 16); };
+    const int vExt = pack2(ext, ext), vC = pack2(open - ext, open - ext);
+    const v2us one2 = {1, 1};
+    const int base = nb + (G - g) * ext - open;    // X-form of a true 0 in this lane's column j0 - 1 (and E~ of column j0)
+
+    auto left_h = [&](int erow, int P) -> int {    // true H(row, virtual column)
+        const int i = erow - P;
+        return (i >= 0 && col_pen) ? -(open + i * ext) : 0;
+    };
+    auto below_f = [&](int erow, int P) -> int {   // true F flowing into row erow at a virtual column
+        const int i = erow - P;
+        return (i >= 0 && col_pen) ? -(open + i * ext) : -open;
+    };
+
+    int HA[R], HB[R], E[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        HA[k] = pack2(base + left_h(g * R + k, PvA), base + left_h(g * R + k, PvB));
+        HB[k] = HA[k]; E[k] = HA[k];
+    }
+    int Hout = HA[R - 1];
+    int Fout = pack2(base + open + below_f((g + 1) * R, PvA), base + open + below_f((g + 1) * R, PvB));
+    int diag0 = (g == 0) ? pack2(base, base) : pack2(base + left_h(g * R - 1, PvA), base + left_h(g * R - 1, PvB));
+    // row above lane 0: penalised -> H(-1, j) = -(open + j ext): a constant in the skewed X-form; free -> 0: grows by ext per column
+    int topX = row_pen ? pack2(nb + (G + 1) * ext - 2 * open, nb + (G + 1) * ext - 2 * open)
+                       : pack2(nb + (G + 1) * ext - open, nb + (G + 1) * ext - open);     // lane 0, column 0
+    const int topStep = row_pen ? 0 : vExt;
+    int skewX = pack2((G - g + 1) * ext - open, (G - g + 1) * ext - open);   // X-form minus nb minus true value, this lane's column j0; += ext
+
+    const v2s rl1 = PK(pack2(rlA - 1, rlB - 1)), rlv = PK(pack2(rlA, rlB));
+    int jj = ((-g) & 0xFFFF) * 0x00010001;
+    int res = 0;                           // X-form (skew of column rlen-1) of H(qlen-1, rlen-1)
+    v2s bestrow = PK(0); int bestrowj = 0; // sg, reference end free: first max of the last row, UNSKEWED X-form (nb + H)
+    v2s bestcol = PK(0); int bestcoli = 0; // sg, query end free: first max of the last column (skew of column rlen-1)
+
+    auto load_scores = [&](int symA, int symB, int (&wa)[RS / 4], int (&wb)[RS / 4]) {
+        const int *sa = reinterpret_cast<const int *>(profA + symA * QPS);
+        const int *sb = reinterpret_cast<const int *>(profB + symB * QPS);
+#pragma unroll
+        for (int k = 0; k < RS / 4; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
+    };
+    auto step = [&](const int (&Hold)[R], int (&Hnew)[R], const int (&wa)[RS / 4], const int (&wb)[RS / 4]) {
+        const int Hin = n_shift_up<G>(Hout, topX, g);
+        int F = n_shift_up<G>(Fout, topX, g);            // F^ into row 0 = X of the row above (see the header)
+        int Tpre[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int s = __builtin_amdgcn_perm(wb[k / 4], wa[k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16));
+            Tpre[k] = ((k == 0) ? diag0 : Hold[k - 1]) + s;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int Fe = F - vExt;
+            const int H = I32(n_max3f(PK(Tpre[k]), PK(E[k]), PK(Fe)));
+            const int X = H - vC;
+            E[k] = I32(n_max3f(PK(E[k]), PK(X), PK(X)));
+            F = I32(n_max3f(PK(Fe), PK(X), PK(X)));
+            Hnew[k] = X;
+        }
+        diag0 = Hin;
+        Hout = Hnew[R - 1];
+        Fout = F;
+
+        // ---- captures ----
+        const v2s jv = PK(jj);
+        const int mLast = m_eq(jv, rl1);                  // this lane is at column rlen-1
+        res = n_bfi(mLast, Hout, res);
+        if (s2_end) {
+            const v2s cand = PK(I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, Hout) - __builtin_bit_cast(v2us, skewX))));   // nb + true H
+            const int imp = m_lt(bestrow, cand) & m_ult(jv, rlv);
+            bestrow = PK(n_bfi(imp, I32(cand), I32(bestrow)));
+            bestrowj = n_bfi(imp, jj, bestrowj);
+        }
+        if (s1_end && __builtin_amdgcn_ballot_w64(mLast != 0) != 0) {
+            const v2s Pv = PK(pack2(PvA, PvB));
+            v2s cm = PK(0); int krow = 0;
+            v2s vals[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int er = g * R + k;
+                const int mreal = ~m_lt(PK(pack2(er, er)), Pv);
+                vals[k] = PK(Hnew[k] & mreal);
+                cm = n_max3f(cm, vals[k], vals[k]);
+            }
+#pragma unroll
+            for (int k = R - 1; k >= 0; --k) {
+                const int er = g * R + k;
+                krow = n_bfi(m_eq(vals[k], cm), pack2(er, er), krow);
+            }
+            const int imp = m_lt(bestcol, cm) & mLast;
+            bestcol = PK(n_bfi(imp, I32(cm), I32(bestcol)));
+            bestcoli = n_bfi(imp, krow, bestcoli);
+        }
+        jj = I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, jj) + one2));
+        skewX = I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, skewX) + __builtin_bit_cast(v2us, vExt)));   // halves may be negative: per-half add
+        topX += topStep;
+    };
+
+    const int T = (max_rlen + G - 1 + 1) & ~1;
+    int w0a[RS / 4], w0b[RS / 4], w1a[RS / 4], w1b[RS / 4];
+    load_scores(rsA[0], rsB[0], w0a, w0b);
+    int nsA = rsA[1], nsB = rsB[1];
+    for (int t = 0; t < T; t += 2) {
+        load_scores(nsA, nsB, w1a, w1b);
+        nsA = rsA[t + 2]; nsB = rsB[t + 2];
+        __builtin_amdgcn_sched_barrier(0);
+        step(HA, HB, w0a, w0b);
+        __builtin_amdgcn_sched_barrier(0);
+        load_scores(nsA, nsB, w0a, w0b);
+        nsA = rsA[t + 3]; nsB = rsB[t + 3];
+        __builtin_amdgcn_sched_barrier(0);
+        step(HB, HA, w1a, w1b);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- combine (all captured values -> true scores) ---------------------------------------
+    unsigned keyA = ((unsigned)(I32(bestcol) & 0xFFFF) << 16) | (0xFFFFu - (unsigned)(bestcoli & 0xFFFF));
+    unsigned keyB = ((unsigned)((unsigned)I32(bestcol) >> 16) << 16) | (0xFFFFu - ((unsigned)bestcoli >> 16));
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) {
+        const unsigned oa = __shfl_xor(keyA, off, 64), ob = __shfl_xor(keyB, off, 64);
+        keyA = oa > keyA ? oa : keyA;
+        keyB = ob > keyB ? ob : keyB;
+    }
+    const int lastlane = slot * G + G - 1;
+    const int resL = __shfl(res, lastlane, 64);
+    const int browL = __shfl(I32(bestrow), lastlane, 64), browjL = __shfl(bestrowj, lastlane, 64);
+    if (g == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long pi = ptab[5 * (2 * slot + h) + 4];
+            if (pi >= 0) {
+                const int ql = (int)ptab[5 * (2 * slot + h) + 1], rl = (int)ptab[5 * (2 * slot + h) + 3];
+                const int P = QP - ql;
+                const int unsk = nb + (rl - 1 + G) * ext - open + ext;          // X-form of a true 0 at column rlen-1
+                const int corner = (int)(h ? ((unsigned)resL >> 16) : (resL & 0xFFFF)) - unsk;
+                pmx_record_t rec;
+                rec.flags = 0;
+                if (!s1_end && !s2_end) { rec.score = corner; rec.end_query = ql - 1; rec.end_ref = rl - 1; }
+                else {
+                    int best = -2147483647 - 1, ei = 0, ej = 0;
+                    if (s2_end) {
+                        best = (int)(h ? ((unsigned)browL >> 16) : (browL & 0xFFFF)) - nb;
+                        ei = ql - 1; ej = (int)(h ? ((unsigned)browjL >> 16) : (browjL & 0xFFFF));
+                    }
+                    if (s1_end) {
+                        const unsigned key = h ? keyB : keyA;
+                        const int cv = (int)(key >> 16) - unsk;
+                        if (cv > best) { best = cv; ei = (int)(0xFFFFu - (key & 0xFFFFu)) - P; ej = rl - 1; }
+                    }
+                    rec.score = best; rec.end_query = ei; rec.end_ref = ej;
+                }
+                out[pi] = rec;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------ host side ----
 template <int G, int R>
 static int launch_nwsg(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
@@ -378,6 +663,28 @@ static int launch_nwsg(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
     return e == hipSuccess ? 0 : -(int)e;
 }
 
+template <int G, int R>
+static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
+                        pmx_record_t *d_out, hipStream_t stream)
+{
+    constexpr int RS = (R + 3) / 4 * 4, NP = 2 * (64 / G);
+    const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
+    const size_t lds = (size_t)NP * (m.msize + 1) * G * RS + (size_t)NP * RP +
+                       (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
+    if (lds > 160 * 1024) return 1;
+    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R>)); if (rc) return rc; }
+    const bool sg = mode == PMX_MODE_SG;
+    const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
+    const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
+    const long long blocks = (b.n + NP - 1) / NP;
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R>), dim3((unsigned)blocks), dim3(64), lds, stream,
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
+                       m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
 // 0 launched, 1 not eligible (caller uses the general kernel), <0 HIP error
 int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                       pmx_record_t *d_out, hipStream_t stream, const char **kernel_name)
@@ -392,6 +699,27 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
     const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);
     if (lo < -15000 || hi > 15000) return 1;
     const int q = b.max_qlen;
+    // second-generation arithmetic (skewed columns, byte profile, VOP2): the profile byte score + open must fit,
+    // and the proven range plus the skew growth must fit the exact window with the bias chosen here
+    {
+        const long long growth = (long long)(b.max_rlen + 2 * 64 + 4) * ext;
+        const long long span = (hi - lo) + growth + 2LL * open + (m.max > 0 ? m.max : 0) + 2048;
+        if (!getenv("PMX_NWSG16_GEN1") && m.min + open >= 0 && m.max + open <= 255 && span < 31743) {
+            const int nb = (int)(1536 - lo + open);
+#define TRYV(GG, RR, NAME)                                                      \
+            if (q <= (GG) * (RR) - 1) {                                         \
+                int rc = launch_nwsgv<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
+                if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; } \
+            }
+            TRYV(8, 20, "pmx_nwsg16v_kernel<8,20>")
+            TRYV(16, 16, "pmx_nwsg16v_kernel<16,16>")
+            TRYV(32, 10, "pmx_nwsg16v_kernel<32,10>")
+            TRYV(32, 16, "pmx_nwsg16v_kernel<32,16>")
+            TRYV(64, 16, "pmx_nwsg16v_kernel<64,16>")
+            TRYV(64, 32, "pmx_nwsg16v_kernel<64,32>")
+#undef TRYV
+        }
+    }
 #define TRYN(GG, RR, NAME)                                                      \
     if (q <= (GG) * (RR) - 1) {                                                 \
         int rc = launch_nwsg<GG, RR>(b, m, mode, sg_flags, open, ext, d_out, stream); \

@@ -370,6 +370,30 @@ def test_nwsg16_blosum62_all_instantiations(pkg, orc, maxlen):
         _nwsg_case(pkg, orc, mode, None, qs, rs, 11, 1, pm, om)
 
 
+def test_nwsg16_first_generation_kernel(pkg, orc, monkeypatch):
+    """the first-generation kernel (int16 profile, -inf scores) stays in use when score + open does not fit a byte"""
+    rng = np.random.default_rng(3250)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 300, 1, 159) + random_seqs(rng, 40, 200, 500)
+    rs = [mutate(rng, q, 0.1, 0.04) if i % 3 else random_seqs(rng, 1, 1, 300)[0] for i, q in enumerate(qs)]
+    _nwsg_case(pkg, orc, 0, None, qs, rs, 2, 2, pm, om)            # mismatch + open < 0
+    monkeypatch.setenv("PMX_NWSG16_GEN1", "1")
+    for sg in (None, orc.S1_BEG | orc.S2_END, orc.S2_BEG, orc.S1_END):
+        _nwsg_case(pkg, orc, 1, sg, qs, rs, 5, 2, pm, om)
+    _nwsg_case(pkg, orc, 0, None, qs, rs, 5, 2, pm, om)
+
+
+def test_nwsg16_long_references_and_skew_growth(pkg, orc):
+    """second-generation kernel: the column skew grows with the reference length; long references, ext up to open"""
+    rng = np.random.default_rng(3260)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 40, 50, 300)
+    rs = [random_seqs(rng, 1, 2000, 3000)[0][:1500] + mutate(rng, q, 0.05, 0.02) + random_seqs(rng, 1, 200, 1200)[0] for q in qs]
+    for mode, sg in ((0, None), (1, None), (1, orc.S2_BEG | orc.S2_END), (1, orc.S1_BEG | orc.S1_END)):
+        _nwsg_case(pkg, orc, mode, sg, qs, rs, 5, 2, pm, om, expect_kernel=None)
+        _nwsg_case(pkg, orc, mode, sg, qs, rs, 3, 3, pm, om, expect_kernel=None)
+
+
 def test_nwsg16_falls_back_outside_the_exact_window(pkg, orc):
     """long sequences with large penalties leave the biased 16-bit window: the general kernel takes over"""
     rng = np.random.default_rng(3300)
