@@ -37,6 +37,12 @@ struct PmxBatch {
 int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                     pmx_record_t *d_out, hipStream_t stream, const char **kernel_name);
 
+// Traceback variant of the second-generation nw/sg kernel (pmx_nwsg16.hip); the walk lives in pmx_trace16.hip.
+int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
+                         int *variant, int *Tmax, size_t *trace_bytes);
+int pmx_launch_nwsgv_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
+                           pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream);
+
 // Length-sorted processing order for ragged batches (pmx_sort.hip).
 size_t pmx_sort_scratch_bytes(long long n);
 int pmx_build_length_perm(const int64_t *d_roff, long long n, void *scratch, const unsigned **perm_out, hipStream_t stream);

@@ -374,7 +374,12 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
 //     the E / F chain that carries -(open + k ext) there (open >= ext); the row above lane 0 is the
 //     closed form of that chain (a constant in the skewed domain) or, for a free reference begin, 0;
 //   * the bias nb is chosen by the host from the proven value range (room for the skew growth).
-template <int G, int R>
+//   * TR: the same sweep also writes the 4-bit traceback cells pmx_trace16.hip's walk reads (bit 3 ND: T < H,
+//     bit 2 NDL: F < H, bit 1 EO: E of the next column opened, bit 0 FO: F of the next row opened).  Each
+//     decision is the sign of one packed difference, pushed into a packed plane (16 bits = 4 rows per
+//     half): 3 instructions per decision and 2 cells.  Per lane and step one 16-byte store, coalesced over the
+//     wave: [pair A rows 0-7, A rows 8-15, B rows 0-7, B rows 8-15], row 0 in the top nibble.  
+template <int G, int R, bool TR>
 __global__ __launch_bounds__(64)
 void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                         const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
@@ -382,8 +387,9 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
                         int msize, int open, int ext, int RP, int q_shared,
                         int col_pen, int row_pen, int s1_end, int s2_end, int nb,
                         const unsigned *__restrict__ perm,
-                        pmx_record_t *__restrict__ out)
+                        pmx_record_t *__restrict__ out, uint32_t *__restrict__ tbuf, int Tmax)
 {
+    static_assert(!TR || R == 16, "trace: four packed planes of 4 rows");
     constexpr int RS = (R + 3) / 4 * 4;      // profile bytes reserved per lane (whole dwords)
     constexpr int QP = G * R;                // logical rows (query bottom-aligned in them)
     constexpr int QPS = G * RS;              // profile bytes per (pair, symbol)
@@ -522,10 +528,23 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 #pragma unroll
         for (int k = 0; k < RS / 4; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
     };
-    auto step = [&](const int (&Hold)[R], int (&Hnew)[R], const int (&wa)[RS / 4], const int (&wb)[RS / 4]) {
+    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * Tmax) * 256 + lane * 4 : nullptr;
+    const v2s two2 = {2, 2}, sh15 = {15, 15};
+    auto push = [&](v2s &pl, int a, int b) {         // pl = 2 * pl + (a < b), per half
+        const v2s bit = PK(I32(__builtin_bit_cast(v2us, PK(a) - PK(b)) >> __builtin_bit_cast(v2us, sh15)));
+        int r;                                        // asm: left alone the compiler regroups the pushes into more instructions
+        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(I32(pl)), "v"(I32(two2)), "v"(I32(bit)));
+        pl = PK(r);
+    };
+    auto step = [&](const int (&Hold)[R], int (&Hnew)[R], const int (&wa)[RS / 4], const int (&wb)[RS / 4], int t) {
         const int Hin = n_shift_up<G>(Hout, topX, g);
         int F = n_shift_up<G>(Fout, topX, g);            // F^ into row 0 = X of the row above (see the header)
         int Tpre[R];
+        v2s plane[TR ? R / 4 : 1];
+        if (TR) {
+#pragma unroll
+            for (int x = 0; x < R / 4; ++x) plane[x] = PK(0);
+        }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int s = __builtin_amdgcn_perm(wb[k / 4], wa[k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16));
@@ -537,9 +556,23 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             const int Fe = F - vExt;
             const int H = I32(n_max3f(PK(Tpre[k]), PK(E[k]), PK(Fe)));
             const int X = H - vC;
+            if (TR) {
+                push(plane[k / 4], Tpre[k], H);      // ND
+                push(plane[k / 4], Fe, H);           // NDL
+                push(plane[k / 4], E[k], X);         // EO: E(j) - ext < H - open in the skewed forms
+                push(plane[k / 4], Fe, X);           // FO: F - ext < H - open
+            }
             E[k] = I32(n_max3f(PK(E[k]), PK(X), PK(X)));
             F = I32(n_max3f(PK(Fe), PK(X), PK(X)));
             Hnew[k] = X;
+        }
+        if (TR) {
+            uint4 w;
+            w.x = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x05040100);   // A: rows 0-3 | rows 4-7
+            w.y = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x05040100);
+            w.z = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x07060302);   // B
+            w.w = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x07060302);
+            *reinterpret_cast<uint4 *>(tw + (size_t)t * 256) = w;
         }
         diag0 = Hin;
         Hout = Hnew[R - 1];
@@ -588,12 +621,12 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         load_scores(nsA, nsB, w1a, w1b);
         nsA = rsA[t + 2]; nsB = rsB[t + 2];
         __builtin_amdgcn_sched_barrier(0);
-        step(HA, HB, w0a, w0b);
+        step(HA, HB, w0a, w0b, t);
         __builtin_amdgcn_sched_barrier(0);
         load_scores(nsA, nsB, w0a, w0b);
         nsA = rsA[t + 3]; nsB = rsB[t + 3];
         __builtin_amdgcn_sched_barrier(0);
-        step(HB, HA, w1a, w1b);
+        step(HB, HA, w1a, w1b, t + 1);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -663,26 +696,73 @@ static int launch_nwsg(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
     return e == hipSuccess ? 0 : -(int)e;
 }
 
-template <int G, int R>
+template <int G, int R, bool TR = false>
 static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
-                        pmx_record_t *d_out, hipStream_t stream)
+                        pmx_record_t *d_out, hipStream_t stream, uint32_t *tbuf = nullptr, int Tmax = 0)
 {
     constexpr int RS = (R + 3) / 4 * 4, NP = 2 * (64 / G);
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
     const size_t lds = (size_t)NP * (m.msize + 1) * G * RS + (size_t)NP * RP +
                        (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
     if (lds > 160 * 1024) return 1;
-    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R>)); if (rc) return rc; }
+    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R, TR>)); if (rc) return rc; }
     const bool sg = mode == PMX_MODE_SG;
     const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R>), dim3((unsigned)blocks), dim3(64), lds, stream,
+    hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
-                       m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out);
+                       m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
+}
+
+// Second-generation eligibility: the profile byte score + open must fit, and the proven value range plus
+// the skew growth must fit the exact window with the bias chosen here.  Returns the bias, or 0.
+static int nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext)
+{
+    if (getenv("PMX_NWSG16_GEN1")) return 0;
+    if (m.msize > PMX_MAX_FAST_MSIZE - 1 || open < ext || ext < 0 || b.max_rlen > 30000) return 0;
+    const long long lo = -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
+    const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);
+    const long long growth = (long long)(b.max_rlen + 2 * 64 + 4) * ext;
+    const long long span = (hi - lo) + growth + 2LL * open + (m.max > 0 ? m.max : 0) + 2048;
+    if (m.min + open < 0 || m.max + open > 255 || span >= 31743) return 0;
+    return (int)(1536 - lo + open);
+}
+
+// Traceback variant (global / semi-global): shapes with 16 rows per lane.  Trace layout: per block
+// Tmax steps x 64 lanes x 16 bytes.
+int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
+                         int *variant, int *Tmax, size_t *trace_bytes)
+{
+    if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
+    if (b.q_shared || b.perm || !nwsgv_bias(b, m, open, ext)) return 1;
+    int G;
+    if (b.max_qlen <= 8 * 16 - 1) { *variant = 0; G = 8; }
+    else if (b.max_qlen <= 16 * 16 - 1) { *variant = 1; G = 16; }
+    else if (b.max_qlen <= 32 * 16 - 1) { *variant = 2; G = 32; }
+    else if (b.max_qlen <= 64 * 16 - 1) { *variant = 3; G = 64; }
+    else return 1;
+    const int NP = 2 * (64 / G);
+    *Tmax = (b.max_rlen + G - 1 + 1) & ~1;
+    *trace_bytes = (size_t)((b.n + NP - 1) / NP) * (size_t)*Tmax * 64 * 16;
+    return 0;
+}
+
+int pmx_launch_nwsgv_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
+                           pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream)
+{
+    const int nb = nwsgv_bias(b, m, open, ext);
+    if (!nb) return 1;
+    switch (variant) {
+    case 0: return launch_nwsgv<8, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 1: return launch_nwsgv<16, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 2: return launch_nwsgv<32, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 3: return launch_nwsgv<64, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    }
+    return 1;
 }
 
 // 0 launched, 1 not eligible (caller uses the general kernel), <0 HIP error
@@ -694,32 +774,26 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
     if (m.msize > PMX_MAX_FAST_MSIZE - 1) return 1;
     if (open < ext || open < 0 || ext < 0) return 1;           // the virtual-row/column fixed points need open >= extend
     if (b.max_rlen > 30000) return 1;
+    const int q = b.max_qlen;
+    // second-generation arithmetic (skewed columns, byte profile, VOP2) whenever its window holds
+    if (const int nb = nwsgv_bias(b, m, open, ext)) {
+#define TRYV(GG, RR, NAME)                                                      \
+        if (q <= (GG) * (RR) - 1) {                                             \
+            int rc = launch_nwsgv<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
+            if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; }   \
+        }
+        TRYV(8, 20, "pmx_nwsg16v_kernel<8,20>")
+        TRYV(16, 16, "pmx_nwsg16v_kernel<16,16>")
+        TRYV(32, 10, "pmx_nwsg16v_kernel<32,10>")
+        TRYV(32, 16, "pmx_nwsg16v_kernel<32,16>")
+        TRYV(64, 16, "pmx_nwsg16v_kernel<64,16>")
+        TRYV(64, 32, "pmx_nwsg16v_kernel<64,32>")
+#undef TRYV
+    }
     // exact window of the biased lanes: every H, E, F, H-open, E-ext and H(diag)+score stays inside
     const long long lo = -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
     const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);
     if (lo < -15000 || hi > 15000) return 1;
-    const int q = b.max_qlen;
-    // second-generation arithmetic (skewed columns, byte profile, VOP2): the profile byte score + open must fit,
-    // and the proven range plus the skew growth must fit the exact window with the bias chosen here
-    {
-        const long long growth = (long long)(b.max_rlen + 2 * 64 + 4) * ext;
-        const long long span = (hi - lo) + growth + 2LL * open + (m.max > 0 ? m.max : 0) + 2048;
-        if (!getenv("PMX_NWSG16_GEN1") && m.min + open >= 0 && m.max + open <= 255 && span < 31743) {
-            const int nb = (int)(1536 - lo + open);
-#define TRYV(GG, RR, NAME)                                                      \
-            if (q <= (GG) * (RR) - 1) {                                         \
-                int rc = launch_nwsgv<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
-                if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; } \
-            }
-            TRYV(8, 20, "pmx_nwsg16v_kernel<8,20>")
-            TRYV(16, 16, "pmx_nwsg16v_kernel<16,16>")
-            TRYV(32, 10, "pmx_nwsg16v_kernel<32,10>")
-            TRYV(32, 16, "pmx_nwsg16v_kernel<32,16>")
-            TRYV(64, 16, "pmx_nwsg16v_kernel<64,16>")
-            TRYV(64, 32, "pmx_nwsg16v_kernel<64,32>")
-#undef TRYV
-        }
-    }
 #define TRYN(GG, RR, NAME)                                                      \
     if (q <= (GG) * (RR) - 1) {                                                 \
         int rc = launch_nwsg<GG, RR>(b, m, mode, sg_flags, open, ext, d_out, stream); \

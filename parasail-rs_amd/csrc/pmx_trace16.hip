@@ -307,14 +307,15 @@ void pmx_trace16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 }
 
 // ---- walk over the 4-bit trace ---------------------------------------------------------------
-template <int G, int R>
+// PACKED: the layout written by pmx_nwsg16v_kernel<G,16,true> (two pairs per slot, 16 bytes per lane and step).
+template <int G, int R, bool PACKED>
 __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
                                   long long n, const uint8_t *mapper, const int16_t *scores, int msize, int open, int ext,
                                   int mode, int Tmax,
                                   const uint32_t *tbuf, const pmx_record_t *recs,
                                   uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg)
 {
-    constexpr int QP = G * R, NP = 64 / G, TW = R / 8;
+    constexpr int QP = G * R, NP = (PACKED ? 2 : 1) * (64 / G), TW = PACKED ? 4 : R / 8;
     const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= n) return;
     const long long qb = qoff[pair], rb = roff[pair];
@@ -325,7 +326,8 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
     const int P = QP - ql;
     auto nib = [&](int i, int j) -> unsigned {         // i >= -1 (row -1 = last virtual row), j >= 0
         const int er = i + P, g = er / R, k = er % R;
-        const uint32_t w = tb[(size_t)(j + g) * (64 * TW) + (slot * G + g) * TW + (k / 8)];
+        const uint32_t w = PACKED ? tb[(size_t)(j + g) * 256 + ((slot >> 1) * G + g) * 4 + (slot & 1) * 2 + (k / 8)]
+                                  : tb[(size_t)(j + g) * (64 * TW) + (slot * G + g) * TW + (k / 8)];
         return (w >> (28 - 4 * (k % 8))) & 0xFu;
     };
     uint32_t *o = ops + ops_off[pair];
@@ -394,7 +396,7 @@ static int launch_trace(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
                        m.msize, open, ext, RP, Tmax, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, d_out, tbuf);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e;
-    hipLaunchKernelGGL((pmx_walk16_kernel<G, R>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream,
+    hipLaunchKernelGGL((pmx_walk16_kernel<G, R, false>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax,
                        (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg);
     e = hipGetLastError();
@@ -411,6 +413,10 @@ int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int ope
     if (m.msize > PMX_MAX_FAST_MSIZE - 1) return 1;
     if (open < ext || open < 0 || ext < 0 || open > 4096) return 1;
     if (b.max_rlen > 30000 || b.q_shared) return 1;
+    if (!getenv("PMX_TRACE16_GEN1") && pmx_nwsgv_trace_plan(b, m, mode, open, ext, variant, Tmax, trace_bytes) == 0) {
+        *variant += 10;            // packed traceback of the second-generation nw/sg kernel
+        return 0;
+    }
     const long long lo = mode == PMX_MODE_SW ? -(2LL * open + 2LL * ext + (m.min < 0 ? -m.min : 0))
                                              : -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
     const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);
@@ -432,6 +438,22 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
                        uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream)
 {
     const bool sw = mode == PMX_MODE_SW;
+    if (variant >= 10) {
+        int rc = pmx_launch_nwsgv_trace(variant - 10, b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, stream);
+        if (rc) return rc;
+#define WALKP(GG) hipLaunchKernelGGL((pmx_walk16_kernel<GG, 16, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream, \
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax,      \
+                       (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg)
+        switch (variant - 10) {
+        case 0: WALKP(8); break;
+        case 1: WALKP(16); break;
+        case 2: WALKP(32); break;
+        default: WALKP(64); break;
+        }
+#undef WALKP
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : -(int)e;
+    }
 #define LT(GG, RR) (sw ? launch_trace<GG, RR, true>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stream) \
                        : launch_trace<GG, RR, false>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stream))
     switch (variant) {

@@ -7,7 +7,8 @@ from util import random_seqs, mutate
 pkg = g.load_pkg()
 rng = np.random.default_rng(1)
 dm = pkg.Matrix.create(b"ACGT", 2, -3)
-qs = random_seqs(rng, 20000, 250, 250)
+N = int(os.environ.get("CFG4_N", "20000"))
+qs = random_seqs(rng, N, 250, 250)
 rs = [mutate(rng, x, 0.1, 0.02) for x in qs]
 al = pkg.Aligner.new().semi_global().matrix(dm).gap_open(5).gap_extend(2).solution_width(16).use_trace().build()
 for _ in range(3):
