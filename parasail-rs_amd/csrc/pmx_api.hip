@@ -1282,8 +1282,15 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
     if (get_devmat(cfg->matrix, &dm)) return -1;
     std::string text;
     cigar_off[0] = 0;
-    // chunks keep the per-launch trace scratch below ~16 GiB (a pair needs at most ~(qlen+64)*(rlen+64)/2 bytes)
-    double chunk_bytes = 16e9;
+    // Chunks bound the per-launch trace scratch: budgeted at one byte per cell of the padded tables (the
+    // general kernel's layout; the fast kernels write 4 bits per cell).  Large chunks matter: the walk is one
+    // lane per pair and hides its dependent-load latency only with many waves in flight.  Up to 96 GB,
+    // at most 45 % of the free HBM.
+    double chunk_bytes = 96e9;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && 0.45 * (double)free_b < chunk_bytes) chunk_bytes = 0.45 * (double)free_b;
+    }
     if (const char *e = getenv("PMX_CIGAR_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
     int64_t c0 = 0;
     while (c0 < n) {

@@ -7,7 +7,7 @@
 #define PMX_MAX_FAST_MSIZE 32      // fast kernels stage the matrix in LDS as int16[msize*msize]
 
 // Raise the dynamic-LDS limit of a kernel once per (kernel, device); thread-safe.
-int pmx_ensure_lds_attr(const void *kernel);
+int pmx_ensure_lds_attr(const void *kernel, int bytes = 160 * 1024);
 
 // Device-side view of a substitution matrix (built once per parasail_matrix_t, cached).
 struct PmxDevMatrix {

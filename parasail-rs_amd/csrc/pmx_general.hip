@@ -297,7 +297,7 @@ void pmx_general_kernel(const PmxGeneralArgs a)
 #include <mutex>
 #include <set>
 #include <utility>
-int pmx_ensure_lds_attr(const void *kernel)
+int pmx_ensure_lds_attr(const void *kernel, int bytes)
 {
     static std::mutex mx;
     static std::set<std::pair<const void *, int>> done;
@@ -306,7 +306,7 @@ int pmx_ensure_lds_attr(const void *kernel)
     if (e != hipSuccess) return -(int)e;
     std::lock_guard<std::mutex> lk(mx);
     if (done.count({kernel, dev})) return 0;
-    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return -(int)e;
     done.insert({kernel, dev});
     return 0;

@@ -311,25 +311,45 @@ void pmx_trace16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 template <int G, int R, bool PACKED>
 __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
                                   long long n, const uint8_t *mapper, const int16_t *scores, int msize, int open, int ext,
-                                  int mode, int Tmax,
+                                  int mode, int Tmax, int stage /* LDS bytes reserved for each of the block's queries / references, 0 = none */,
                                   const uint32_t *tbuf, const pmx_record_t *recs,
                                   uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg)
 {
+    extern __shared__ unsigned char w_lds[];
     constexpr int QP = G * R, NP = (PACKED ? 2 : 1) * (64 / G), TW = PACKED ? 4 : R / 8;
-    const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // mapper and matrix in LDS: the walk is a chain of dependent loads, keep all but the trace fetch short
+    __shared__ unsigned char s_map[256];
+    __shared__ int16_t s_scores[PMX_MAX_FAST_MSIZE * PMX_MAX_FAST_MSIZE];
+    for (int x = threadIdx.x; x < 256; x += blockDim.x) s_map[x] = mapper[x];
+    for (int x = threadIdx.x; x < msize * msize; x += blockDim.x) s_scores[x] = scores[x];
+    // The block's sequences are contiguous in the packed buffers: stage them in LDS with coalesced loads, so
+    // that the only scattered global access left per step is the trace nibble.
+    const long long p0 = (long long)blockIdx.x * blockDim.x;
+    const long long p1 = p0 + blockDim.x < n ? p0 + blockDim.x : n;
+    const long long qlo = qoff[p0], rlo = roff[p0];
+    if (stage) {
+        const int qn = (int)(qoff[p1] - qlo), rn = (int)(roff[p1] - rlo);
+        for (int x = threadIdx.x; x < qn; x += blockDim.x) w_lds[x] = qbuf[qlo + x];
+        for (int x = threadIdx.x; x < rn; x += blockDim.x) w_lds[stage + x] = rbuf[rlo + x];
+    }
+    __syncthreads();
+    const long long pair = p0 + threadIdx.x;
     if (pair >= n) return;
     const long long qb = qoff[pair], rb = roff[pair];
     const int ql = (int)(qoff[pair + 1] - qb), rl = (int)(roff[pair + 1] - rb);
     const uint8_t *q = qbuf + qb, *r = rbuf + rb;
+    const unsigned char *sq = w_lds + (qb - qlo), *sr = w_lds + stage + (rb - rlo);
     const long long block = pair / NP; const int slot = (int)(pair % NP);
     const uint32_t *tb = tbuf + (size_t)block * Tmax * (64 * TW);
     const int P = QP - ql;
-    auto nib = [&](int i, int j) -> unsigned {         // i >= -1 (row -1 = last virtual row), j >= 0
+    auto ldw = [&](int i, int j) -> uint32_t {         // the trace word holding cell (i, j); 0 outside i >= -1, j >= 0
+        if (i < -1 || j < 0) return 0u;
         const int er = i + P, g = er / R, k = er % R;
-        const uint32_t w = PACKED ? tb[(size_t)(j + g) * 256 + ((slot >> 1) * G + g) * 4 + (slot & 1) * 2 + (k / 8)]
-                                  : tb[(size_t)(j + g) * (64 * TW) + (slot * G + g) * TW + (k / 8)];
-        return (w >> (28 - 4 * (k % 8))) & 0xFu;
+        return PACKED ? tb[(size_t)(j + g) * 256 + ((slot >> 1) * G + g) * 4 + (slot & 1) * 2 + (k / 8)]
+                      : tb[(size_t)(j + g) * (64 * TW) + (slot * G + g) * TW + (k / 8)];
     };
+    auto nibof = [&](uint32_t w, int i) -> unsigned { return (w >> (28 - 4 * (((i + P) % R) % 8))) & 0xFu; };
+    auto nib = [&](int i, int j) -> unsigned { return nibof(ldw(i, j), i); };
     uint32_t *o = ops + ops_off[pair];
     const pmx_record_t rec = recs[pair];
     int i = rec.end_query, j = rec.end_ref, cnt = 0;
@@ -352,9 +372,9 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
             if (sw && rem <= 0) break;                       // ZERO cell
             const unsigned t = nib(i, j);
             if (!(t & 8u)) {
-                const int a = mapper[q[i]], b = mapper[r[j]];
+                const int a = s_map[stage ? sq[i] : q[i]], b = s_map[stage ? sr[j] : r[j]];
                 emit(a == b ? OP_EQ : OP_X);
-                rem -= scores[a * msize + b];
+                if (sw) rem -= s_scores[a * msize + b];
                 --i; --j;
             }
             else if (!(t & 4u)) where = 2;
@@ -376,6 +396,13 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
 }
 
 // ------------------------------------------------------------------------ host side ----
+// LDS bytes per side for staging a 64-pair block's queries / references in the walk (0: too long, read them from HBM)
+static int walk_stage_bytes(const PmxBatch &b)
+{
+    const long long m = 64LL * (b.max_qlen > b.max_rlen ? b.max_qlen : b.max_rlen);
+    return (m <= 60 * 1024) ? (int)((m + 15) / 16 * 16) : 0;
+}
+
 template <int G, int R, bool SW>
 static int launch_trace(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                         pmx_record_t *d_out, uint32_t *tbuf, int Tmax,
@@ -396,8 +423,10 @@ static int launch_trace(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
                        m.msize, open, ext, RP, Tmax, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, d_out, tbuf);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e;
-    hipLaunchKernelGGL((pmx_walk16_kernel<G, R, false>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream,
-                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax,
+    const int stage = walk_stage_bytes(b);
+    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_walk16_kernel<G, R, false>), 128 * 1024); if (rc) return rc; }
+    hipLaunchKernelGGL((pmx_walk16_kernel<G, R, false>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 2 * (size_t)stage, stream,
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage,
                        (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
@@ -441,8 +470,10 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
     if (variant >= 10) {
         int rc = pmx_launch_nwsgv_trace(variant - 10, b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, stream);
         if (rc) return rc;
-#define WALKP(GG) hipLaunchKernelGGL((pmx_walk16_kernel<GG, 16, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream, \
-                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax,      \
+        const int stage = walk_stage_bytes(b);
+#define WALKP(GG) { const int rca = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_walk16_kernel<GG, 16, true>), 128 * 1024); if (rca) return rca; } \
+                  hipLaunchKernelGGL((pmx_walk16_kernel<GG, 16, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 2 * (size_t)stage, stream, \
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage,     \
                        (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg)
         switch (variant - 10) {
         case 0: WALKP(8); break;
