@@ -420,7 +420,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
                             const uint8_t *d_qbuf, const int64_t *d_qoff, int q_shared,
                             const uint8_t *d_rbuf, const int64_t *d_roff,
                             int32_t max_qlen, int32_t max_rlen,
-                            pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream);
+                            pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream, int q_shared_wild = 1);
 
 // One device block + one pinned host block per thread for the one-pair entry: a single H2D, the
 // kernel(s), a single D2H.  (The reference's call is a CPU function of ~20 us; no allocation per call.)
@@ -653,6 +653,14 @@ extern "C" void parasail_profile_free(parasail_profile_t *p)
     delete p->mx;
     free(p->s1); free(p);
 }
+// the query maps to a column beyond the first four of the matrix alphabet somewhere (the perm-table kernel cannot express that)
+static int profile_has_wildcard(const parasail_profile_t *p)
+{
+    for (int i = 0; i < p->s1Len; ++i)
+        if (p->matrix->mapper[(unsigned char)p->s1[i]] >= 4) return 1;
+    return 0;
+}
+
 static int profile_device_query(const parasail_profile_t *p, const uint8_t **out)
 {
     int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
@@ -980,7 +988,8 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
                             const uint8_t *d_qbuf, const int64_t *d_qoff, int q_shared,
                             const uint8_t *d_rbuf, const int64_t *d_roff,
                             int32_t max_qlen, int32_t max_rlen,
-                            pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream)
+                            pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream,
+                            int q_shared_wild /* shared query: it holds a letter beyond the first four (or unknown) */)
 {
     if (check_cfg(cfg)) return -1;
     if (n <= 0) return 0;
@@ -999,7 +1008,8 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         if (rc < 0) { set_err("length sort failed (%d)", rc); return rc; }
     }
     if (fast_sw_eligible(cfg)) {
-        if (!q_shared && n >= 4096 && n < (1LL << 32)) {
+        b.q_has_wildcard = q_shared ? q_shared_wild : 0;
+        if (n >= 4096 && n < (1LL << 32) && !b.q_has_wildcard) {
             // scratch that lets the launcher pick a kernel which hands some pairs back for a second launch
             void *scr = nullptr;
             if (scratch_reserve(((size_t)n + 1) * sizeof(unsigned), &scr, SCR_RETRY)) return -1;
@@ -1155,7 +1165,7 @@ extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_p
     HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     const int rc = run_batch_device(cfg, n, dq.p, nullptr, profile->s1Len, dr.p, dro.p, profile->s1Len, mr,
-                                    drec.p, stats ? dst.p : nullptr, nullptr);
+                                    drec.p, stats ? dst.p : nullptr, nullptr, profile_has_wildcard(profile));
     if (rc) return rc;
     HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
     if (stats) HIP_OR_RET(hipMemcpy(stats_out, dst.p, sizeof(pmx_stats_t) * n, hipMemcpyDeviceToHost));
@@ -1174,7 +1184,7 @@ extern "C" int pmx_align_profile_batch_device(const pmx_config_t *cfg, const par
     const uint8_t *dq = nullptr;
     if (profile_device_query(profile, &dq)) return -1;
     return run_batch_device(cfg, n, dq, nullptr, profile->s1Len, d_rbuf, d_roff, profile->s1Len, max_rlen,
-                            d_out, d_stats_out, stream);
+                            d_out, d_stats_out, stream, profile_has_wildcard(profile));
 }
 
 // CIGAR for a batch.  Fast path: pmx_trace16 (4-bit trace in HBM, on-device walk); otherwise the general

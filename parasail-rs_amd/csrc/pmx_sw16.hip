@@ -79,7 +79,7 @@ __device__ __forceinline__ v2s pk_max3f(v2s a, v2s b, v2s c)   // integer max3 o
 #define FLOOR2 0x80008000   // both halves = -32768 = "zero" of the offset domain
 
 template <int G, int R, int VAR>
-__global__ __launch_bounds__(64, VAR == 6 ? 4 : 1)
+__global__ __launch_bounds__(64, (VAR == 6 && R <= 20) ? 4 : 1)
 void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                      const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
                      long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
@@ -530,22 +530,23 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
     const long long feasible = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0);
     const bool sk = var == 2 && open >= ext && !getenv("PMX_SW16_NO_SKEW") &&
                     feasible + M3_BIAS < (long long)M3_LIMIT(m.max) - (long long)(b.max_rlen + 2 * 64 + 4) * ext;
+    // alphabets of <= 4 letters (+ wildcard): no LDS profile, the v_perm looks the score up (see PT in the kernel)
+    const bool pt = sk && u8ok && m.msize <= 5 && b.retry_list && b.retry_count && !b.q_has_wildcard && !getenv("PMX_SW16_NO_PERMTABLE");
 #define TRY(GG, RR, NAME)                                                       \
     if (q <= (GG) * (RR)) {                                                     \
         constexpr int R4 = (RR) % 4 == 0 ? (RR) : 4;                            \
         const bool u8 = u8ok && (RR) % 4 == 0;                                  \
-        int rc = (u8 && sk) ? launch_one<GG, R4, 5>(b, m, open, ext, d_out, stream)  \
+        int rc = pt ? launch_one<GG, RR, 6>(b, m, open, ext, d_out, stream)     \
+               : (u8 && sk) ? launch_one<GG, R4, 5>(b, m, open, ext, d_out, stream)  \
                : u8 ? launch_one<GG, R4, 3>(b, m, open, ext, d_out, stream)     \
                : (var == 2 && sk) ? launch_one<GG, RR, 4>(b, m, open, ext, d_out, stream)  \
                : var == 2 ? launch_one<GG, RR, 2>(b, m, open, ext, d_out, stream)  \
                : var == 1 ? launch_one<GG, RR, 1>(b, m, open, ext, d_out, stream)  \
                           : launch_one<GG, RR, 0>(b, m, open, ext, d_out, stream); \
-        if (rc <= 0) { if (kernel_name) *kernel_name = var == 2 ? (sk ? NAME "/max3+vop2+skew" : NAME "/max3+vop2") : var == 1 ? NAME "/max3" : NAME; return rc; } \
+        if (rc <= 0) { if (kernel_name) *kernel_name = pt ? NAME "/max3+vop2+skew+permtable" : var == 2 ? (sk ? NAME "/max3+vop2+skew" : NAME "/max3+vop2") : var == 1 ? NAME "/max3" : NAME; return rc; } \
     }
     // byte profile, 8 lanes per pair: half the fill/drain and per-step overhead of <16,10> at the same LDS;
     // rows per lane chosen for the common read lengths (100, 125, 150) so that few rows are padding
-    // alphabets of <= 4 letters (+ wildcard): no LDS profile, the v_perm looks the score up (see PT in the kernel)
-    const bool pt = sk && u8ok && m.msize <= 5 && b.retry_list && b.retry_count && !b.q_has_wildcard && !getenv("PMX_SW16_NO_PERMTABLE");
 #define TRY8(RR)                                                                \
     if (u8ok && q <= 8 * (RR)) {                                                \
         int rc = pt ? launch_one<8, RR, 6>(b, m, open, ext, d_out, stream)      \

@@ -267,6 +267,35 @@ def test_sw16_permtable_variant_and_wildcard_retry(pkg, orc, qmax):
     _fast_case(pkg, orc, same, same, 5, 2, pm, om)
 
 
+@pytest.mark.parametrize("qmax,n,rmax", [(250, 6000, 300), (500, 4200, 400), (1000, 4100, 300), (2000, 4100, 150)])
+def test_sw16_permtable_larger_shapes(pkg, orc, qmax, n, rmax):
+    """the perm-table variant in the 16 / 32 / 64-lane shapes"""
+    rng = np.random.default_rng(1480 + qmax)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, n, max(1, qmax // 2), qmax)
+    qs[0] = random_seqs(rng, 1, qmax, qmax)[0]
+    rs = [mutate(rng, q, 0.08, 0.04)[:rmax] if rng.random() < 0.5 else random_seqs(rng, 1, 1, rmax)[0] for q in qs]
+    for i in range(0, n, 53):
+        q = bytearray(qs[i]); q[int(rng.integers(len(q)))] = ord("N"); qs[i] = bytes(q)
+    _fast_case(pkg, orc, qs, rs, 5, 2, pm, om)
+
+
+def test_sw16_permtable_shared_query(pkg, orc):
+    """profile arm: one shared query; the perm-table variant is used only when the query holds no wildcard"""
+    rng = np.random.default_rng(1490)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    rs = random_seqs(rng, 4500, 20, 400)
+    for q in (random_seqs(rng, 1, 300, 300)[0], random_seqs(rng, 1, 149, 149)[0] + b"N", random_seqs(rng, 1, 1000, 1000)[0]):
+        for k in range(0, len(rs), 9):
+            rs[k] = mutate(rng, q, 0.05, 0.02)[:400]
+        al = pkg.Aligner.new().local().profile(pkg.Profile.new(q, False, pm)).matrix(pm).gap_open(5).gap_extend(2).solution_width(16).build()
+        got = al.align_batch([], rs)
+        qb, qo = orc.pack([q] * len(rs)); rb, ro = orc.pack(rs)
+        want = orc.align_batch(orc.SW, qb, qo, rb, ro, 5, 2, om)
+        assert (got["score"] == want[:, 0]).all() and (got["end_query"] == want[:, 1]).all() \
+            and (got["end_ref"] == want[:, 2]).all() and (got["flags"] == 0).all()
+
+
 def test_sw16_saturating_int16_variant(pkg, orc):
     """scores too large for the max3 lanes (matrix max > 2048) take the saturating-int16 variant"""
     rng = np.random.default_rng(1450)
