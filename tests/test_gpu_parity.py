@@ -231,7 +231,7 @@ def test_sw16_every_arithmetic_variant(pkg, orc, monkeypatch, env):
     for gaps in ((5, 2), (2, 2), (7, 0), (0, 0)):
         _fast_case(pkg, orc, qs, rs, gaps[0], gaps[1], pm, om)
     for qmax in (100, 104, 125, 128, 150, 152):                      # the 8-lane shapes <8,13> <8,16> <8,19>
-        qs = random_seqs(rng, 300, qmax - 30, qmax)
+        qs = random_seqs(rng, 2100, qmax - 30, qmax)                   # > 2048 pairs: the 8-lane shapes are for full chips
         qs[0] = random_seqs(rng, 1, qmax, qmax)[0]
         rs = [mutate(rng, q, 0.1, 0.05) if rng.random() < 0.7 else random_seqs(rng, 1, 1, 200)[0] for q in qs]
         rs[0] = qs[0]
