@@ -294,7 +294,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     const v2s vInitH = V2 ? PK(ZERO2 - I32(vOpen) + skew0) : vZero;
 #pragma unroll
     for (int k = 0; k < R; ++k) { HA[k] = vInitH; HB[k] = vInitH; E[k] = V2 ? vInitH : (M3 ? PK(0) : vZero); Hsave[k] = vZero; }
-    v2s best = PK(ZERO2 + skew0);
+    v2s best = PK(ZERO2 + skew0 - (SK ? I32(vC) : 0));     // SK: X form
     int bestcol = 0;
     int jj = ((-g) & 0xFFFF) * 0x00010001;    // packed column index of this lane
     int Zv = ZERO2 + skew0 + I32(vExt);       // SK: "F^ = 0" of the current column; += ext per step
@@ -343,9 +343,10 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 E[k] = pk_max3f(E[k], X, X);
                 F = pk_max3f(Fe, X, PK(Zv));
                 Hnew[k] = X;
-                Hcur[k] = H;
-                if (k & 1) colmax = pk_max3f(colmax, Hcur[k - 1], H);
-                else if (k == R - 1) colmax = pk_max3f(colmax, H, H);
+                // the column maximum, the running best and the saved strip all live in the X form (H~ - (open - ext)):
+                // the strip itself is what gets saved, no second copy of the column is kept in registers
+                if (k & 1) colmax = pk_max3f(colmax, Hnew[k - 1], X);
+                else if (k == R - 1) colmax = pk_max3f(colmax, X, X);
             } else if (V2) {
                 // Same domain as the max3 variant, but the strips carry H - open and the profile
                 // carries score + open (>= 0), so add and subtract never carry or borrow across
@@ -398,7 +399,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             int hs;
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hs) : "v"(m), "v"(I32(V2 ? Hcur[k] : Hnew[k])), "v"(I32(Hsave[k])));
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hs) : "v"(m), "v"(I32((V2 && !SK) ? Hcur[k] : Hnew[k])), "v"(I32(Hsave[k])));
             Hsave[k] = PK(hs);
         }
         best = SK ? PK(I32(nb) + I32(vExt)) : nb;                           // SK: carried into the next column's skew
@@ -437,7 +438,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
             if ((short)(I32(Hsave[k]) & 0xFFFF) == tA) kA = k;
             if ((short)(I32(Hsave[k]) >> 16) == tB) kB = k;
         }
-        const int unskew = SK ? (G - g + T) * ext : 0;
+        const int unskew = SK ? (G - g + T) * ext - (open - ext) : 0;
         const unsigned sA = (unsigned)(bA - unskew - (M3 ? M3_BIAS : -32768)), sB = (unsigned)(bB - unskew - (M3 ? M3_BIAS : -32768));
         const unsigned rA = g * R + kA, rB = g * R + kB;
         keyA = ((unsigned long long)sA << 32) | ((0xFFFFu - cA) << 16) | (0xFFFFu - rA);
