@@ -778,6 +778,57 @@ def test_banded_matches_full_when_band_is_wide(pkg, orc):
 
 
 # ------------------------------------------------------------------------------- fuzz ----
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_fuzz_fast_kernel_windows(pkg, orc, seed):
+    """Randomised batches aimed at the edges of the fast kernels' exact windows: custom 4-letter matrices whose
+    score + open touches 0 and 255, gap models with ext = 0 / ext = open, long references (large column skew),
+    wildcards and lower case, batch sizes on both sides of the perm-table threshold; score and end positions
+    of all three modes against the oracle."""
+    rng = np.random.default_rng(seed)
+    for it in range(14):
+        match = int(rng.choice([1, 2, 5, 40, 200]))
+        mism = -int(rng.choice([1, 3, 4, 30]))
+        open_ = int(rng.choice([-mism, -mism + 1, 255 - match, 5, 11, 60]))
+        open_ = max(0, min(open_, 255 - match))
+        ext = int(rng.choice([0, 1, 2, open_])) if open_ else 0
+        ext = min(ext, open_)
+        pm, om = pkg.Matrix.create(b"ACGT", match, mism), orc.Matrix.create("ACGT", match, mism)
+        shape = int(rng.integers(0, 4))
+        if shape == 0:   n, qlo, qhi, rlo, rhi = 4500, 20, 150, 20, 200          # perm-table threshold crossed
+        elif shape == 1: n, qlo, qhi, rlo, rhi = 40, 50, 200, 2500, 7000         # long references: skew growth
+        elif shape == 2: n, qlo, qhi, rlo, rhi = 300, 200, 1000, 100, 500
+        else:            n, qlo, qhi, rlo, rhi = 2200, 90, 128, 60, 150
+        qs = random_seqs(rng, n, qlo, qhi)
+        rs = []
+        for q in qs:
+            r = random_seqs(rng, 1, rlo, rhi)[0]
+            if rng.random() < 0.6:
+                pos = int(rng.integers(0, max(1, len(r) - len(q))))
+                r = (r[:pos] + mutate(rng, q, 0.1, 0.04) + r[pos + len(q):])[:rhi]
+            rs.append(r)
+        for i in range(0, n, 29):
+            q = bytearray(qs[i]); q[int(rng.integers(len(q)))] = ord("N"); qs[i] = bytes(q)
+        for i in range(3, n, 31):
+            r = bytearray(rs[i]); r[int(rng.integers(len(r)))] = ord("n"); rs[i] = bytes(r)
+        qs[0] = qs[0].lower()
+        qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+        for mode in (2, 1, 0):
+            if mode != 2 and shape == 1 and rng.random() < 0.5:
+                continue
+            sg = int(rng.integers(1, 16)) if mode == 1 else None
+            b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext)
+            [b.global_, b.semi_global, b.local][mode]()
+            if mode == 1:
+                qg = [t for f, t in ((orc.S1_BEG, "prefix"), (orc.S1_END, "suffix")) if sg & f]
+                dg = [t for f, t in ((orc.S2_BEG, "prefix"), (orc.S2_END, "suffix")) if sg & f]
+                b.allow_query_gaps(qg).allow_ref_gaps(dg)
+            got = b.build().align_batch(qs, rs)                     # `sat`: promotion hides overflow
+            want = orc.align_batch(mode, qb, qo, rb, ro, open_, ext, om, sg_flags=sg if sg is not None else orc.SG_ALL)
+            bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
+            assert len(bad) == 0, (seed, it, match, mism, open_, ext, shape, mode, sg, bad[:5], got[bad[:5]], want[bad[:5]])
+            assert (got["flags"] == 0).all()
+
+
 def test_fuzz_every_dispatch_path(pkg, orc):
     """Randomised differential test over the whole batch dispatcher: random mode, free-end set, gap
     model, matrix, width, length distribution and output kind (records / stats / CIGAR), every
