@@ -85,9 +85,42 @@ def pmc_traffic_bytes():
         return None
 
 
+def cpu_reference_baseline(qbuf, rbuf, cores):
+    """If the box has the reference's real library (a system libparasail), time `parasail_sw_striped_16`
+    on all usable cores, one thread per core over its slice of pairs (the pattern of the reference's
+    tests/test_parasail.rs:702-717).  Returns None when it is absent (it is, in the build image)."""
+    try:
+        from oracle import parasail_probe
+        lib = parasail_probe.load()
+        if lib is None:
+            return None
+        from concurrent.futures import ThreadPoolExecutor
+        sample = 65536
+        qs = [qbuf[k * LEN:(k + 1) * LEN].tobytes() for k in range(sample)]
+        rs = [rbuf[k * LEN:(k + 1) * LEN].tobytes() for k in range(sample)]
+        per = (sample + cores - 1) // cores
+        def work(c):
+            return parasail_probe.align_batch(lib, b"sw_striped_16", qs[c * per:(c + 1) * per], rs[c * per:(c + 1) * per],
+                                              OPEN, EXT, b"ACGT", MATCH, MISMATCH)
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(work, range(cores)))                # warm-up
+            t0 = time.perf_counter()
+            parts = list(ex.map(work, range(cores)))
+            t = time.perf_counter() - t0
+        out = np.array([x for p in parts for x in p], dtype=np.int32)
+        return {"value": round(sample * LEN * LEN / t / 1e9, 3), "unit": "GCUPS", "cores": int(cores), "kind": "reference",
+                "sample": "%d of the same 150x150 pairs, system libparasail parasail_sw_striped_16 via ctypes, one thread per core, "
+                          "%.2f s wall" % (sample, t)}, out
+    except Exception:
+        return None
+
+
 def cpu_baseline(qbuf, qoff, rbuf, roff):
     """The CPU port of the reference's kernel class (Farrar striped int16, AVX2 + OpenMP), all host
-    cores, on a bounded sample of the same workload."""
+    cores, on a bounded sample of the same workload (or the real library, if the box has one)."""
+    ref = cpu_reference_baseline(qbuf, rbuf, usable_cores())
+    if ref is not None:
+        return ref
     from oracle import oracle as orc
     m = orc.Matrix.create("ACGT", MATCH, MISMATCH)
     cores = usable_cores()

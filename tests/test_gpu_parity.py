@@ -120,6 +120,48 @@ def test_scan_and_diag_names_are_aliases(pkg, orc):
             assert not res.is_blocked() and not res.is_banded()
 
 
+def test_cfg1_protein_pair_fixture(pkg):
+    """BASELINE config 1: one protein pair, BLOSUM62, gaps 11/1, through Aligner::align() semantics (one-off, profile
+    arm, stats, traceback) and through the batch entries; expected values from tests/golden/cfg1_protein_pair.json"""
+    import json
+    fx = json.load(open("tests/golden/cfg1_protein_pair.json"))
+    q, r = fx["query"].encode(), fx["ref"].encode()
+    pm = pkg.Matrix.from_name("blosum62")
+    for name, sel in (("sw", "local"), ("nw", "global_"), ("sg", "semi_global")):
+        c = fx["cases"][name]
+        def mk():
+            b = pkg.Aligner.new().matrix(pm).gap_open(fx["open"]).gap_extend(fx["extend"])
+            getattr(b, sel)()
+            return b
+        res = mk().build().align(q, r)                                   # e.g. sw_striped_sat
+        assert (res.get_score(), res.get_end_query(), res.get_end_ref()) == (c["score"], c["end_query"], c["end_ref"])
+        st = mk().use_stats().build().align(q, r)
+        assert (st.get_score(), st.get_matches(), st.get_similar(), st.get_length()) == \
+            (c["score"], c["matches"], c["similar"], c["length"])
+        tr = mk().use_trace().build()
+        assert tr.align(q, r).get_cigar(q, r) == c["cigar"]
+        prof = mk().profile(pkg.Profile.new(q, False, pm)).build().align(None, r)
+        assert prof.get_score() == c["score"]
+        rec = mk().solution_width(16).build().align_batch([q, q], [r, r])
+        assert (rec["score"] == c["score"]).all() and (rec["end_query"] == c["end_query"]).all() and (rec["end_ref"] == c["end_ref"]).all()
+        rec, cig = tr.align_batch_cigar([q], [r])
+        assert cig[0] == c["cigar"] and rec["score"][0] == c["score"]
+
+
+def test_cross_check_against_system_parasail_if_present(pkg):
+    """if the box has the reference's real library, compare with it; the build image has none."""
+    from oracle import parasail_probe
+    lib = parasail_probe.load()
+    if lib is None:
+        pytest.skip("parasail oracle unavailable; parity is against the in-repo scalar oracle (pinned by the reference's KATs)")
+    rng = np.random.default_rng(99)
+    qs = random_seqs(rng, 300, 20, 150)
+    rs = [mutate(rng, q, 0.1, 0.03) for q in qs]
+    want = parasail_probe.align_batch(lib, b"sw_striped_16", qs, rs, 5, 2, b"ACGT", 2, -3)
+    got = pkg.Aligner.new().local().matrix(pkg.Matrix.create(b"ACGT", 2, -3)).gap_open(5).gap_extend(2).solution_width(16).build().align_batch(qs, rs)
+    assert [tuple(int(x) for x in (g["score"], g["end_query"], g["end_ref"])) for g in got] == want
+
+
 def test_accessor_guards(pkg):
     res = pkg.Aligner.new().build().align(b"ACGT", b"ACGT")
     for f, exc in (("get_matches", pkg.NoStats), ("get_length", pkg.NoStats), ("get_score_table", pkg.NoTable),

@@ -159,3 +159,18 @@ def test_striped_cpu_port_blosum62(orc):
     want = orc.align_batch(orc.SW, qb, qo, rb, ro, 11, 1, m)
     got, _ = orc.cpu_sw_striped16_batch(qb, qo, rb, ro, 11, 1, m, threads=2)
     assert (got == want).all()
+
+
+def test_cfg1_fixture_is_reproduced(orc):
+    """BASELINE config 1 (one protein pair, BLOSUM62 11/1): the committed oracle outputs (tests/golden/make_cfg1.py)
+    pin the scalar oracle against regressions; the GPU suite replays the same pair through the mirror."""
+    import json
+    fx = json.load(open("tests/golden/cfg1_protein_pair.json"))
+    m = orc.Matrix.from_file("tests/golden/blosum62.txt")
+    q, r = fx["query"].encode(), fx["ref"].encode()
+    for name, mode in (("sw", orc.SW), ("nw", orc.NW), ("sg", orc.SG)):
+        w = orc.align(mode, q, r, fx["open"], fx["extend"], m, stats=True, trace=True)
+        c = fx["cases"][name]
+        assert (w.score, w.end_query, w.end_ref, w.matches, w.similar, w.length) == \
+            (c["score"], c["end_query"], c["end_ref"], c["matches"], c["similar"], c["length"])
+        assert orc.cigar(w) == c["cigar"]
