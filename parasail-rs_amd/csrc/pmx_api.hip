@@ -1190,10 +1190,19 @@ extern "C" int pmx_align_profile_batch_device(const pmx_config_t *cfg, const par
 // CIGAR for a batch.  Fast path: pmx_trace16 (4-bit trace in HBM, on-device walk); otherwise the general
 // kernel with byte trace tables and pmx_walk_kernel.  Only the run-length ops come back to the host, which
 // renders the text.  One chunk = one set of launches; chunks bound the trace scratch.
+// PMX_TIMING=1: stage times of the batch CIGAR entry on stderr
+struct StageTimer {
+    bool on; double t0; const char *what;
+    static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+    StageTimer() : on(getenv("PMX_TIMING") != nullptr), t0(now()), what("") {}
+    void done(const char *stage) { if (on) { (void)hipDeviceSynchronize(); const double t = now(); fprintf(stderr, "[pmx timing] %-28s %8.3f ms\n", stage, (t - t0) * 1e3); t0 = t; } }
+};
+
 static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
                        const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
                        pmx_record_t *out, std::string &text, int64_t *cigar_off /* n+1, cigar_off[0] preset */)
 {
+    StageTimer tm;
     int32_t mq = 0, mr = 0; bool bad = false;
     host_maxlens(n, qoff, &mq, &bad); host_maxlens(n, roff, &mr, &bad);
     if (bad || qoff[0] != 0 || roff[0] != 0) { set_err("bad offsets"); return -1; }
@@ -1206,12 +1215,14 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
     drec.alloc(n); dnops.alloc(n); dbeg.alloc(2 * n);
     uint32_t *dops = nullptr;
     if (scratch_reserve((size_t)ops_off[n] * sizeof(uint32_t), (void **)&dops, SCR_OPS)) return -1;
+    tm.done("host prep + device alloc");
     HIP_OR_RET(hipMemcpy(dq.p, qbuf, qbytes, hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dqo.p, qoff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(doo.p, ops_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
 
+    tm.done("H2D");
     PmxBatch b = {dq.p, dqo.p, dr.p, dro.p, n, mq, mr, 0, nullptr, nullptr, nullptr, 0};
     int variant = 0, Tmax = 0; size_t tbytes = 0;
     int rc;
@@ -1249,31 +1260,28 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
         if (rc) { set_err("walk kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
         HIP_OR_RET(hipDeviceSynchronize());      // dto is released on scope exit
     }
-    // only the runs actually produced come back: nops first, then a dense copy of the ops
-    std::vector<int32_t> nops(n);
+    tm.done("sweep + walk kernels");
+    // The CIGAR text is rendered on the device: text lengths come back (4 bytes per pair), the host turns them
+    // into offsets, the text itself is written there and copied back in one piece.
     HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
-    HIP_OR_RET(hipMemcpy(nops.data(), dnops.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    std::vector<int64_t> dense_off(n + 1);
-    dense_off[0] = 0;
-    for (int64_t k = 0; k < n; ++k) dense_off[k + 1] = dense_off[k] + nops[k];
-    DevBuf<int64_t> ddo; DevBuf<uint32_t> ddense;
-    ddo.alloc(n + 1); ddense.alloc((size_t)dense_off[n]);
-    HIP_OR_RET(hipMemcpy(ddo.p, dense_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
-    rc = pmx_launch_compact_ops(dops, doo.p, dnops.p, ddo.p, ddense.p, n, nullptr);
-    if (rc) { set_err("compaction kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
-    std::vector<uint32_t> ops((size_t)dense_off[n] + 1);
-    HIP_OR_RET(hipMemcpy(ops.data(), ddense.p, sizeof(uint32_t) * (size_t)dense_off[n], hipMemcpyDeviceToHost));
-    char num[16];
-    for (int64_t k = 0; k < n; ++k) {
-        for (int64_t t = dense_off[k]; t < dense_off[k + 1]; ++t) {
-            const uint32_t o = ops[(size_t)t];
-            uint32_t v = o >> 4; int len = 0;
-            do { num[len++] = (char)('0' + v % 10); v /= 10; } while (v);
-            while (len) text.push_back(num[--len]);
-            text.push_back(BAM_OPS[o & 0xF]);
-        }
-        cigar_off[k + 1] = (int64_t)text.size();
-    }
+    DevBuf<int32_t> dtl; dtl.alloc(n);
+    rc = pmx_launch_cigar_textlen(dops, doo.p, dnops.p, dtl.p, n, nullptr);
+    if (rc) { set_err("cigar length kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    std::vector<int32_t> tl(n);
+    HIP_OR_RET(hipMemcpy(tl.data(), dtl.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    std::vector<int64_t> toff(n + 1);
+    toff[0] = 0;
+    for (int64_t k = 0; k < n; ++k) toff[k + 1] = toff[k] + tl[k];
+    DevBuf<int64_t> dtoff; DevBuf<char> dtext;
+    dtoff.alloc(n + 1); dtext.alloc((size_t)toff[n] + 1);
+    HIP_OR_RET(hipMemcpy(dtoff.p, toff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    rc = pmx_launch_cigar_render(dops, doo.p, dnops.p, dtoff.p, dtext.p, n, nullptr);
+    if (rc) { set_err("cigar render kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    const size_t base = text.size();
+    text.resize(base + (size_t)toff[n]);
+    if (toff[n]) HIP_OR_RET(hipMemcpy(&text[base], dtext.p, (size_t)toff[n], hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < n; ++k) cigar_off[k + 1] = (int64_t)base + toff[k + 1];
+    tm.done("render + D2H");
     return 0;
 }
 
@@ -1302,10 +1310,15 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && 0.45 * (double)free_b < chunk_bytes) chunk_bytes = 0.45 * (double)free_b;
     }
     if (const char *e = getenv("PMX_CIGAR_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
+    // equal shares: as many chunks as the budget needs, each with about the same number of table bytes
+    double total_bytes = 0;
+    for (int64_t k = 0; k < n; ++k) total_bytes += 1.0 * (double)(qoff[k + 1] - qoff[k] + 64) * (double)(roff[k + 1] - roff[k] + 64);
+    const double nchunks = total_bytes > chunk_bytes ? (double)(int64_t)(total_bytes / chunk_bytes + 1.0) : 1.0;
+    const double share = total_bytes / nchunks + 1.0;
     int64_t c0 = 0;
     while (c0 < n) {
         int64_t c1 = c0; double bytes = 0;
-        while (c1 < n && (c1 == c0 || bytes < chunk_bytes)) {
+        while (c1 < n && (c1 == c0 || bytes < share)) {
             bytes += 1.0 * (double)(qoff[c1 + 1] - qoff[c1] + 64) * (double)(roff[c1 + 1] - roff[c1] + 64);
             ++c1;
         }

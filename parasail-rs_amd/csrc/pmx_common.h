@@ -103,8 +103,9 @@ struct PmxWalkArgs {
     uint32_t *ops; const int64_t *ops_off; int32_t *nops; int32_t *beg; /* 2 per pair */
 };
 int pmx_launch_walk(const PmxWalkArgs &a, hipStream_t stream);
-int pmx_launch_compact_ops(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops,
-                           const int64_t *dense_off, uint32_t *dense, long long n, hipStream_t stream);
+int pmx_launch_cigar_textlen(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops, int32_t *textlen, long long n, hipStream_t stream);
+int pmx_launch_cigar_render(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops,
+                            const int64_t *text_off, char *text, long long n, hipStream_t stream);
 
 // Collect the indices of records whose flags intersect `mask`: list[0..*count) (device), any order.
 int pmx_launch_collect_saturated(const pmx_record_t *rec, long long n, int64_t *list, int *count, int mask, hipStream_t stream);

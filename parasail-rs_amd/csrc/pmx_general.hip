@@ -423,24 +423,47 @@ int pmx_launch_collect_saturated(const pmx_record_t *rec, long long n, int64_t *
     return e == hipSuccess ? 0 : -(int)e;
 }
 
-// Dense copy of the run-length ops: pair k's nops[k] runs move from ops[ops_off[k]..] to dense[dense_off[k]..].
-__global__ void pmx_compact_ops_kernel(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops,
-                                       const int64_t *dense_off, uint32_t *dense, long long n)
+// CIGAR text on the device: pass 1 measures each pair's text, pass 2 writes it at the caller's offsets
+// ("<len><op>" per run, ops = BAM codes, "MIDNSHP=X").
+__device__ __forceinline__ int pmx_digits(uint32_t v) { int d = 1; while (v >= 10) { v /= 10; ++d; } return d; }
+__global__ void pmx_cigar_textlen_kernel(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops, int32_t *textlen, long long n)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint32_t *src = ops + ops_off[k];
-    uint32_t *dst = dense + dense_off[k];
-    const int m = nops[k];
-    for (int t = 0; t < m; ++t) dst[t] = src[t];
+    int len = 0;
+    for (int t = 0; t < nops[k]; ++t) len += pmx_digits(src[t] >> 4) + 1;
+    textlen[k] = len;
 }
-
-int pmx_launch_compact_ops(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops,
-                           const int64_t *dense_off, uint32_t *dense, long long n, hipStream_t stream)
+__global__ void pmx_cigar_render_kernel(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops,
+                                        const int64_t *text_off, char *text, long long n)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t *src = ops + ops_off[k];
+    char *dst = text + text_off[k];
+    for (int t = 0; t < nops[k]; ++t) {
+        const uint32_t o = src[t];
+        uint32_t v = o >> 4;
+        const int d = pmx_digits(v);
+        for (int x = d - 1; x >= 0; --x) { dst[x] = (char)('0' + v % 10); v /= 10; }
+        dst[d] = "MIDNSHP=X"[o & 0xF];
+        dst += d + 1;
+    }
+}
+int pmx_launch_cigar_textlen(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops, int32_t *textlen, long long n, hipStream_t stream)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(pmx_compact_ops_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream,
-                       ops, ops_off, nops, dense_off, dense, n);
+    hipLaunchKernelGGL(pmx_cigar_textlen_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, ops, ops_off, nops, textlen, n);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
+int pmx_launch_cigar_render(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops,
+                            const int64_t *text_off, char *text, long long n, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pmx_cigar_render_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, ops, ops_off, nops, text_off, text, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
