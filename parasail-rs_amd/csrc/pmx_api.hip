@@ -1128,12 +1128,41 @@ extern "C" int pmx_align_batch(const pmx_config_t *cfg, int64_t n,
     dq.alloc(qbytes); dr.alloc(rbytes); dqo.alloc(n + 1); dro.alloc(n + 1); drec.alloc(n);
     const bool stats = cfg->want & PMX_WANT_STATS;
     if (stats) { if (!stats_out) { set_err("stats requested without a stats buffer"); return -1; } dst.alloc(n); }
-    HIP_OR_RET(hipMemcpy(dq.p, qbuf, qbytes, hipMemcpyHostToDevice));
-    HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dqo.p, qoff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
-    const int rc = pmx_align_batch_device(cfg, n, dq.p, dqo.p, dr.p, dro.p, mq, mr, drec.p, stats ? dst.p : nullptr, nullptr);
-    if (rc) return rc;
+    if (n >= 262144 && !(cfg->want & PMX_WANT_SORTED)) {
+        // Large uniform batches: the sequence bytes go up in slices on a copy stream while the previous slice
+        // is already being aligned on a compute stream (the offsets are absolute, so a slice is just a pointer
+        // shift); over PCIe the transfer is 3-4x the kernel time, this hides the kernel behind it.
+        static thread_local hipStream_t s_copy = nullptr, s_comp = nullptr;
+        static thread_local hipEvent_t s_ev[8];
+        static thread_local int s_dev = -1;
+        int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
+        if (s_dev != dev) {
+            HIP_OR_RET(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+            HIP_OR_RET(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
+            for (auto &e : s_ev) HIP_OR_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            s_dev = dev;
+        }
+        const int K = 8;
+        for (int sl = 0; sl < K; ++sl) {
+            const int64_t a = n * sl / K, e = n * (sl + 1) / K;
+            if (e <= a) continue;
+            HIP_OR_RET(hipMemcpyAsync(dq.p + qoff[a], qbuf + qoff[a], (size_t)(qoff[e] - qoff[a]), hipMemcpyHostToDevice, s_copy));
+            HIP_OR_RET(hipMemcpyAsync(dr.p + roff[a], rbuf + roff[a], (size_t)(roff[e] - roff[a]), hipMemcpyHostToDevice, s_copy));
+            HIP_OR_RET(hipEventRecord(s_ev[sl], s_copy));
+            HIP_OR_RET(hipStreamWaitEvent(s_comp, s_ev[sl], 0));
+            const int rc = pmx_align_batch_device(cfg, e - a, dq.p, dqo.p + a, dr.p, dro.p + a, mq, mr, drec.p + a,
+                                                  stats ? dst.p + a : nullptr, s_comp);
+            if (rc) { (void)hipStreamSynchronize(s_comp); return rc; }
+        }
+        HIP_OR_RET(hipStreamSynchronize(s_comp));
+    } else {
+        HIP_OR_RET(hipMemcpy(dq.p, qbuf, qbytes, hipMemcpyHostToDevice));
+        HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
+        const int rc = pmx_align_batch_device(cfg, n, dq.p, dqo.p, dr.p, dro.p, mq, mr, drec.p, stats ? dst.p : nullptr, nullptr);
+        if (rc) return rc;
+    }
     HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
     if (stats) HIP_OR_RET(hipMemcpy(stats_out, dst.p, sizeof(pmx_stats_t) * n, hipMemcpyDeviceToHost));
     return 0;
