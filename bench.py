@@ -172,7 +172,9 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # PMX_BENCH_FORCE_DIST=1 (rehearsal on a one-GPU box): take the exchange path with a single rank
+    multi = world > 1 or bool(os.environ.get("PMX_BENCH_FORCE_DIST"))
+    if multi:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -192,7 +194,7 @@ def main():
     from importlib import import_module
     sharding = import_module("parasail_rs_amd.sharding")
     counts = [n] * world
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    comm_stream = torch.cuda.Stream(device=dev) if multi else None
     pending = []
 
     def step(k, events=None):
@@ -207,7 +209,7 @@ def main():
                                LEN, LEN, out.data_ptr(), None, stream.cuda_stream)
         if events is not None:
             events[1].record(stream)
-        if world > 1:
+        if multi:
             # exchange step: records of this step go to rank 0 while the next step computes
             if backend == "nccl":
                 done = torch.cuda.Event()
