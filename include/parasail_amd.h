@@ -262,7 +262,11 @@ int pmx_align_batch(const pmx_config_t *cfg, int64_t n,
                     pmx_record_t *out, pmx_stats_t *stats_out /* NULL unless WANT_STATS */);
 
 /* Device-resident buffers (all pointers are device pointers on the current device),
- * asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream). */
+ * asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ * Internal scratch (length-sort permutation, retry list of the perm-table kernel) belongs to the calling
+ * host thread and is reused by its next call: a thread may queue calls back to back on ONE stream; to run
+ * on several streams at once, call from several threads.  Internal record flag values (PMX_FLAG_RERUN, 4)
+ * never survive to the caller. */
 int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
                            const uint8_t *d_qbuf, const int64_t *d_qoff,
                            const uint8_t *d_rbuf, const int64_t *d_roff,
