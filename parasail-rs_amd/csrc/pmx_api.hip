@@ -942,7 +942,8 @@ static int check_cfg(const pmx_config_t *cfg)
 
 static bool fast_sw_eligible(const pmx_config_t *cfg)
 {
-    return cfg->mode == PMX_MODE_SW && (cfg->want & ~PMX_WANT_SORTED) == 0 && cfg->width != 8 &&
+    // (width 8 included: for local alignment the saturation rule only needs the score, see PmxBatch::sat_above)
+    return cfg->mode == PMX_MODE_SW && (cfg->want & ~PMX_WANT_SORTED) == 0 &&
            cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE;
 }
 
@@ -999,7 +1000,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
     DevMat dm;
     if (get_devmat(cfg->matrix, &dm)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, max_qlen, max_rlen, q_shared, nullptr, nullptr, nullptr, 0};
+    PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, max_qlen, max_rlen, q_shared, nullptr, nullptr, nullptr, 0, 0};
     const int want = cfg->want & ~PMX_WANT_SORTED;
     if ((cfg->want & PMX_WANT_SORTED) && n >= 64 && n < (1LL << 32)) {
         void *scr = nullptr;
@@ -1009,6 +1010,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
     }
     if (fast_sw_eligible(cfg)) {
         b.q_has_wildcard = q_shared ? q_shared_wild : 0;
+        b.sat_above = cfg->width == 8 ? 127 : 0;
         if (n >= 4096 && n < (1LL << 32) && !b.q_has_wildcard) {
             // scratch that lets the launcher pick a kernel which hands some pairs back for a second launch
             void *scr = nullptr;
@@ -1026,7 +1028,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
             // (the max3 variant of the fast kernel is exact up to 29 696 - max score; beyond that it sets
             //  PMX_FLAG_RERUN and the pair is redone here whatever the requested width)
             if (bound_score <= 27000) return 0;
-            const int mask = PMX_FLAG_RERUN | (cfg->width == 16 ? 0 : PMX_FLAG_SATURATED);
+            const int mask = PMX_FLAG_RERUN | ((cfg->width == 16 || cfg->width == 8) ? 0 : PMX_FLAG_SATURATED);
             DevBuf<int64_t> list; DevBuf<int> cnt;
             list.alloc((size_t)n); cnt.alloc(1);
             int rc2 = pmx_launch_collect_saturated(d_out, n, list.p, cnt.p, mask, st);
@@ -1043,7 +1045,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
             a.rbuf = d_rbuf; a.roff = d_roff; a.n = count; a.index = list.p; a.max_rlen = max_rlen;
             a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
             a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
-            a.bits = cfg->width == 16 ? 16 : 32; a.bound = bnd.p; a.bound_stride = (long long)stride2; a.rec = d_out;
+            a.bits = cfg->width == 16 ? 16 : cfg->width == 8 ? 8 : 32; a.bound = bnd.p; a.bound_stride = (long long)stride2; a.rec = d_out;
             rc2 = pmx_launch_general(a, false, st);
             if (rc2) { set_err("promotion launch failed (%d)", rc2); return rc2 < 0 ? rc2 : -1; }
             HIP_OR_RET(hipStreamSynchronize(st));      // scratch is released on return
@@ -1252,7 +1254,7 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
     HIP_OR_RET(hipMemcpy(doo.p, ops_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
 
     tm.done("H2D");
-    PmxBatch b = {dq.p, dqo.p, dr.p, dro.p, n, mq, mr, 0, nullptr, nullptr, nullptr, 0};
+    PmxBatch b = {dq.p, dqo.p, dr.p, dro.p, n, mq, mr, 0, nullptr, nullptr, nullptr, 0, 0};
     int variant = 0, Tmax = 0; size_t tbytes = 0;
     int rc;
     if (cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&

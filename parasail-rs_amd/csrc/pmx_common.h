@@ -28,6 +28,8 @@ struct PmxBatch {
     unsigned *retry_list;    // optional scratch, n entries + one int: lets the sw16 launcher use kernels that hand
     int *retry_count;        //   some pairs back for a second launch (decided on the device, no host sync)
     int q_has_wildcard;      // shared query only: it holds a letter beyond the first four of the alphabet
+    int sat_above;           // sw16 only, 0 = off: scores above this set PMX_FLAG_SATURATED (width 8: 127; local H >= 0, so the
+                             //   maximum H is the score and the oracle's saturation rule needs nothing else)
 };
 #define PMX_FLAG_RETRY16 4   // internal record flag: redo with the LDS-profile variant of the fast kernel
 

@@ -89,6 +89,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                      const unsigned *__restrict__ perm,
                      const int *__restrict__ n_dev /* != nullptr: the pair count is read from the device (retry launches) */,
                      unsigned *__restrict__ retry_list, int *__restrict__ retry_count /* PT: pairs to redo */,
+                     int sat_above /* scores above this are flagged PMX_FLAG_SATURATED (INT_MAX: never) */,
                      pmx_record_t *__restrict__ out)
 {
     if (n_dev) n = *n_dev;
@@ -463,6 +464,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 rec.end_query = 0xFFFF - (int)(key & 0xFFFF);
                 if (M3) rec.flags = (rec.score + M3_BIAS >= limit) ? PMX_FLAG_RERUN : 0;   // left the exact range: redo in 32 bits
                 else rec.flags = rec.score > 32767 ? PMX_FLAG_SATURATED : 0;
+                if (rec.score > sat_above) rec.flags |= PMX_FLAG_SATURATED;
                 if (PT && ((wild >> h) & 1)) {                                              // wildcard in the query: redo with the LDS profile
                     rec.flags = PMX_FLAG_RETRY16;
                     retry_list[atomicAdd(retry_count, 1)] = (unsigned)pi;
@@ -497,7 +499,7 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
     hipLaunchKernelGGL((pmx_sw16_kernel<G, R, VAR>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                        m.msize, open, ext, RP, b.q_shared, M3_LIMIT(m.max) - (VAR >= 4 ? (b.max_rlen + 2 * G + 4) * ext : 0), b.perm,
-                       n_dev, b.retry_list, b.retry_count, d_out);
+                       n_dev, b.retry_list, b.retry_count, b.sat_above > 0 ? b.sat_above : 2147483647, d_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e;
     if (PT) {

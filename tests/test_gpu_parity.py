@@ -338,6 +338,29 @@ def test_sw16_permtable_shared_query(pkg, orc):
             and (got["end_ref"] == want[:, 2]).all() and (got["flags"] == 0).all()
 
 
+def test_sw16_width8_batches(pkg, orc):
+    """`sw_striped_8` batches run in the fast kernel: local H >= 0, so the 8-bit saturation rule is "score > 127" """
+    rng = np.random.default_rng(1495)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 5000, 10, 150)
+    rs = [mutate(rng, q, 0.1, 0.03) if i % 2 else random_seqs(rng, 1, 10, 150)[0] for i, q in enumerate(qs)]
+    al = pkg.Aligner.new().local().matrix(pm).gap_open(5).gap_extend(2).solution_width(8).build()
+    assert al.fn_name == "sw_striped_8"
+    got = al.align_batch(qs, rs)
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    want = orc.align_batch(orc.SW, qb, qo, rb, ro, 5, 2, om)
+    sat = want[:, 0] > 127
+    assert sat.sum() > 100 and (~sat).sum() > 100
+    assert ((got["flags"] & pkg.FLAG_SATURATED) != 0).tolist() == sat.tolist()
+    ok = ~sat
+    assert (got["score"][ok] == want[ok, 0]).all() and (got["end_query"][ok] == want[ok, 1]).all() and (got["end_ref"][ok] == want[ok, 2]).all()
+    for k in (0, 1, 2, 3):
+        w = orc.align(orc.SW, qs[k], rs[k], 5, 2, om, bits=8)
+        assert bool(got["flags"][k] & pkg.FLAG_SATURATED) == bool(w.saturated)
+        one = al.align(qs[k], rs[k])
+        assert one.is_saturated() == bool(w.saturated)
+
+
 def test_sw16_saturating_int16_variant(pkg, orc):
     """scores too large for the max3 lanes (matrix max > 2048) take the saturating-int16 variant"""
     rng = np.random.default_rng(1450)
