@@ -409,11 +409,11 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     };
 
     // software pipeline: scores of step t+1 are fetched from LDS while step t computes
-    const int T = (max_rlen + G - 1 + 1) & ~1;           // even number of steps (extra pad column is harmless)
+    const int T = max_rlen + G - 1;                      // steps: the last lane's last real column
     int w0a[RS / WR], w0b[RS / WR], w1a[RS / WR], w1b[RS / WR];
     load_scores(rsA[0], rsB[0], w0a, w0b);
     int nsA = rsA[1], nsB = rsB[1];
-    for (int t = 0; t < T; t += 2) {
+    for (int t = 0; t + 1 < T; t += 2) {
         load_scores(nsA, nsB, w1a, w1b);
         nsA = rsA[t + 2]; nsB = rsB[t + 2];
         __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads ahead of the step they overlap with
@@ -425,6 +425,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         step(HB, HA, w1a, w1b);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (T & 1) step(HA, HB, w0a, w0b);                   // odd step count: one more (its scores are already loaded)
 
     // ---- per lane: first row of the saved strip that holds the best ---------------------
     unsigned long long keyA, keyB;
