@@ -136,9 +136,17 @@ def cpu_baseline(qbuf, qoff, rbuf, roff):
     rate = 16384 / max(t, 1e-6)
     sample = int(min(N_PAIRS, max(16384, rate * 2.0)))  # ~2 s wall
     t, used, out = run(sample)
+    cpu = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": round(sample * LEN * LEN / t / 1e9, 3), "unit": "GCUPS", "cores": int(used), "kind": "port",
-            "sample": "%d of the same 150x150 pairs, striped int16 AVX2 + OpenMP (oracle/pmx_striped_cpu.c), "
-                      "%.2f s wall" % (sample, t)}, out
+            "sample": "%d of the same 150x150 pairs, restated CPU baseline (not parasail): striped int16 AVX2 + OpenMP "
+                      "(oracle/pmx_striped_cpu.c, gcc -O3 -mavx2 -fopenmp), %s, %.2f s wall" % (sample, cpu, t)}, out
 
 
 def main():
