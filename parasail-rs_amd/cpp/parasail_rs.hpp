@@ -450,6 +450,43 @@ public:
         if (rc) throw Error(ErrorKind::Batch, pmx_last_error());
         return out;
     }
+    // additive: the profile arm for many references (pmx_align_profile_batch; the aligner was built with .profile())
+    std::vector<pmx_record_t> align_profile_batch(const std::vector<Bytes> &refs, std::vector<pmx_stats_t> *stats = nullptr) const
+    {
+        if (!profile_) throw Error(ErrorKind::Batch, "aligner has no profile");
+        std::string rb; std::vector<int64_t> ro(1, 0);
+        for (auto &r : refs) { rb += r; ro.push_back((int64_t)rb.size()); }
+        pmx_config_t cfg = config_;
+        cfg.matrix = matrix->inner;
+        std::vector<pmx_record_t> out(refs.size());
+        if (cfg.want & PMX_WANT_STATS) { if (!stats) throw Error(ErrorKind::Batch, "stats aligner needs a stats vector"); stats->resize(refs.size()); }
+        const int rc = pmx_align_profile_batch(&cfg, profile_->inner, (int64_t)refs.size(), (const uint8_t *)rb.data(), ro.data(),
+                                               out.data(), (cfg.want & PMX_WANT_STATS) ? stats->data() : nullptr);
+        if (rc) throw Error(ErrorKind::Batch, pmx_last_error());
+        return out;
+    }
+    // additive: records + CIGAR text per pair, traceback done on the device (pmx_align_batch_cigar)
+    std::vector<pmx_record_t> align_batch_cigar(const std::vector<Bytes> &queries, const std::vector<Bytes> &refs,
+                                                std::vector<std::string> &cigars) const
+    {
+        if (queries.size() != refs.size()) throw Error(ErrorKind::Batch, "queries and references differ in count");
+        std::string qb, rb; std::vector<int64_t> qo(1, 0), ro(1, 0);
+        for (auto &q : queries) { qb += q; qo.push_back((int64_t)qb.size()); }
+        for (auto &r : refs) { rb += r; ro.push_back((int64_t)rb.size()); }
+        pmx_config_t cfg = config_;
+        cfg.matrix = matrix->inner;
+        cfg.want &= ~PMX_WANT_STATS;
+        std::vector<pmx_record_t> out(refs.size());
+        std::vector<int64_t> coff(refs.size() + 1);
+        char *text = nullptr;
+        const int rc = pmx_align_batch_cigar(&cfg, (int64_t)refs.size(), (const uint8_t *)qb.data(), qo.data(), (const uint8_t *)rb.data(),
+                                             ro.data(), out.data(), &text, coff.data());
+        if (rc) throw Error(ErrorKind::Batch, pmx_last_error());
+        cigars.resize(refs.size());
+        for (size_t k = 0; k < refs.size(); ++k) cigars[k].assign(text + coff[k], text + coff[k + 1]);
+        pmx_free(text);
+        return out;
+    }
 
     std::shared_ptr<Matrix> matrix;
     int gap_open = 0, gap_extend = 0;

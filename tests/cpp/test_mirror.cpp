@@ -94,6 +94,15 @@ int main()
         auto al = Aligner::builder().local().matrix(Matrix::create("ACGT", 2, -3)).gap_open(5).gap_extend(2).solution_width(16).build();
         auto out = al.align_batch({"ACGTACGTAC", "TTTT", "ACGT"}, {"ACGTACGTAC", "AAAA", "TACGTT"});
         CHECK(out[0].score == 20 && out[0].end_query == 9 && out[1].score == 0 && out[2].score == 8 && out[2].end_ref == 4);
+        std::vector<std::string> cig;
+        auto tr = Aligner::builder().global().matrix(Matrix::create("ACGT", 2, -3)).gap_open(5).gap_extend(2).use_trace().build();
+        auto rec = tr.align_batch_cigar({"ACGTACGTAC", "ACGT"}, {"ACGTACGTAC", "ACGGT"}, cig);
+        CHECK(rec[0].score == 20 && cig[0] == "10=" && cig[1] == "2=1D2=" && rec[1].score == 3);
+        auto m = Matrix::create("ACGT", 2, -3);
+        auto prof = Profile::new_("ACGTACGTAC", false, m);
+        auto pal = Aligner::builder().local().profile(std::move(prof)).matrix(std::move(m)).gap_open(5).gap_extend(2).build();
+        auto pr = pal.align_profile_batch({"ACGTACGTAC", "TTTT", "GTACG"});
+        CHECK(pr[0].score == 20 && pr[1].score == 2 && pr[2].score == 10);
     }
     printf("cpp mirror ok\n"); fflush(stdout);
     return 0;
