@@ -1263,6 +1263,7 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
         if (scratch_reserve(tbytes, (void **)&tbuf, SCR_TRACE)) return -1;
         rc = pmx_launch_trace16(variant, b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, drec.p, tbuf, Tmax,
                                 dops, doo.p, dnops.p, dbeg.p, nullptr);
+        g_last_kernel = variant >= 20 ? "pmx_sw16_kernel/packed trace + pmx_walk16_kernel" : variant >= 10 ? "pmx_nwsg16v_kernel/packed trace + pmx_walk16_kernel" : "pmx_trace16_kernel + pmx_walk16_kernel";
         if (rc) { set_err("trace16 launch failed (%d)", rc); return rc < 0 ? rc : -1; }
     } else {
         std::vector<int64_t> tab_off(n + 1);
@@ -1288,6 +1289,7 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
         w.mapper = dm.d.mapper; w.mode = cfg->mode; w.trace_table = dtrace; w.tab_off = dto.p; w.rec = drec.p;
         w.ops = dops; w.ops_off = doo.p; w.nops = dnops.p; w.beg = dbeg.p;
         rc = pmx_launch_walk(w, nullptr);
+        g_last_kernel = "pmx_general_kernel + pmx_walk_kernel";
         if (rc) { set_err("walk kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
         HIP_OR_RET(hipDeviceSynchronize());      // dto is released on scope exit
     }

@@ -39,6 +39,11 @@ struct PmxBatch {
 int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                     pmx_record_t *d_out, hipStream_t stream, const char **kernel_name);
 
+// Traceback variant of the local kernel (pmx_sw16.hip, VAR 7): same trace layout, rows top-aligned.
+int pmx_sw16_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, int *variant, int *Tmax, size_t *trace_bytes);
+int pmx_launch_sw16_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
+                          pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream);
+
 // Traceback variant of the second-generation nw/sg kernel (pmx_nwsg16.hip); the walk lives in pmx_trace16.hip.
 int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
                          int *variant, int *Tmax, size_t *trace_bytes);

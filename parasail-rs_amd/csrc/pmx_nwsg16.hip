@@ -739,12 +739,14 @@ int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
 {
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
     if (b.q_shared || b.perm || !nwsgv_bias(b, m, open, ext)) return 1;
-    int G;
-    if (b.max_qlen <= 8 * 16 - 1) { *variant = 0; G = 8; }
-    else if (b.max_qlen <= 16 * 16 - 1) { *variant = 1; G = 16; }
-    else if (b.max_qlen <= 32 * 16 - 1) { *variant = 2; G = 32; }
-    else if (b.max_qlen <= 64 * 16 - 1) { *variant = 3; G = 64; }
-    else return 1;
+    int G = 0;
+    for (int v = 0; v < 4 && !G; ++v) {                  // the first shape that holds the query and fits the LDS (launch_nwsgv's condition)
+        const int g = 8 << v, np = 2 * (64 / g);
+        const size_t lds = (size_t)np * (m.msize + 1) * g * 16 + (size_t)np * (b.max_rlen + 2 * g + 12) +
+                           (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)np * 40;
+        if (b.max_qlen <= g * 16 - 1 && lds <= 160 * 1024) { *variant = v; G = g; }
+    }
+    if (!G) return 1;
     const int NP = 2 * (64 / G);
     *Tmax = (b.max_rlen + G - 1 + 1) & ~1;
     *trace_bytes = (size_t)((b.n + NP - 1) / NP) * (size_t)*Tmax * 64 * 16;

@@ -90,6 +90,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                      const int *__restrict__ n_dev /* != nullptr: the pair count is read from the device (retry launches) */,
                      unsigned *__restrict__ retry_list, int *__restrict__ retry_count /* PT: pairs to redo */,
                      int sat_above /* scores above this are flagged PMX_FLAG_SATURATED (INT_MAX: never) */,
+                     uint32_t *__restrict__ tbuf, int Tmax /* VAR 7: 4-bit traceback cells, layout of pmx_nwsg16v_kernel<..,true> */,
                      pmx_record_t *__restrict__ out)
 {
     if (n_dev) n = *n_dev;
@@ -100,7 +101,9 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                                        //   v_perm itself -- table = the 4 scores of this step's reference symbol (one dword per pair),
                                        //   selector = the lane's query letters (one VGPR per row).  Query wildcards cannot be
                                        //   expressed: such pairs are flagged PMX_FLAG_RETRY16 and redone with the LDS profile.
-    constexpr bool U8 = VAR == 3 || VAR == 5 || PT;   // + one-byte profile entries (score + open fits 0..255): half the LDS, same v_perm count
+    constexpr bool TR = VAR == 7;      // VAR 5 + packed 4-bit traceback output (see pmx_nwsg16.hip: same bits, same layout; rows top-aligned here)
+    static_assert(!TR || R == 16, "trace: four packed planes of 4 rows");
+    constexpr bool U8 = VAR == 3 || VAR == 5 || PT || TR;   // + one-byte profile entries (score + open fits 0..255): half the LDS, same v_perm count
     constexpr bool SK = VAR >= 4;      // + column-skewed values (everything in column j carries +(j+G)*ext): E needs no subtract
     constexpr int EB = U8 ? 1 : 2;     // bytes per profile entry
     constexpr int WR = U8 ? 4 : 2;     // rows per loaded dword
@@ -312,12 +315,25 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 #pragma unroll
         for (int k = 0; k < RS / WR; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
     };
-    auto step = [&](const v2s (&Hold)[R], v2s (&Hnew)[R], const int (&wa)[RS / WR], const int (&wb)[RS / WR]) {
+    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * Tmax) * 256 + lane * 4 : nullptr;
+    auto push = [&](v2s &pl, v2s a, v2s b) {        // pl = 2 * pl + (a < b), per half
+        const v2u fifteen = {15, 15};
+        const int bit = I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2u, a - b) >> fifteen));
+        int r;
+        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(I32(pl)), "v"(0x00020002), "v"(bit));
+        pl = PK(r);
+    };
+    auto step = [&](const v2s (&Hold)[R], v2s (&Hnew)[R], const int (&wa)[RS / WR], const int (&wb)[RS / WR], int t) {
         const int Hin = group_shift_up<G>(Hout, SK ? Zv - I32(vOpen) : HNEUTRAL, g); // H(i0-1, j)
         v2s F = PK(group_shift_up<G>(Fout, SK ? Zv : ZERO2, g));                       // F(i0, j)
         v2s colmax = SK ? PK(0) : vZero;
         v2s Hcur[R];                                           // V2 only: this column's H (the strips hold H - open)
         v2s Tpre[R], Epre[R];                                  // V2 only: hoisted independent adds / subtracts
+        v2s plane[TR ? R / 4 : 1];
+        if (TR) {
+#pragma unroll
+            for (int x = 0; x < R / 4; ++x) plane[x] = PK(0);
+        }
         if (V2) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
@@ -341,6 +357,12 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 const v2s Fe = PK(I32(F) - I32(vExt));            // F~ of this row (F^ - ext), also F^'s extension
                 H = pk_max3f(Tpre[k], E[k], Fe);
                 const v2s X = PK(I32(H) - I32(vC));
+                if (TR) {
+                    push(plane[k / 4], Tpre[k], H);      // ND
+                    push(plane[k / 4], Fe, H);           // NDL
+                    push(plane[k / 4], E[k], X);         // EO
+                    push(plane[k / 4], Fe, X);           // FO
+                }
                 E[k] = pk_max3f(E[k], X, X);
                 F = pk_max3f(Fe, X, PK(Zv));
                 Hnew[k] = X;
@@ -384,6 +406,14 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 colmax = pk_max(colmax, H);
             }
         }
+        if (TR) {
+            uint4 w;
+            w.x = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x05040100);   // A: rows 0-3 | rows 4-7
+            w.y = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x05040100);
+            w.z = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x07060302);   // B
+            w.w = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x07060302);
+            *reinterpret_cast<uint4 *>(tw + (size_t)t * 256) = w;
+        }
         diag0 = PK(Hin);
         Hout = I32(Hnew[R - 1]);
         Fout = I32(F);
@@ -417,15 +447,15 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         load_scores(nsA, nsB, w1a, w1b);
         nsA = rsA[t + 2]; nsB = rsB[t + 2];
         __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads ahead of the step they overlap with
-        step(HA, HB, w0a, w0b);
+        step(HA, HB, w0a, w0b, t);
         __builtin_amdgcn_sched_barrier(0);
         load_scores(nsA, nsB, w0a, w0b);
         nsA = rsA[t + 3]; nsB = rsB[t + 3];
         __builtin_amdgcn_sched_barrier(0);
-        step(HB, HA, w1a, w1b);
+        step(HB, HA, w1a, w1b, t + 1);
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (T & 1) step(HA, HB, w0a, w0b);                   // odd step count: one more (its scores are already loaded)
+    if (T & 1) step(HA, HB, w0a, w0b, T - 1);                   // odd step count: one more (its scores are already loaded)
 
     // ---- per lane: first row of the saved strip that holds the best ---------------------
     unsigned long long keyA, keyB;
@@ -480,10 +510,10 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 
 template <int G, int R, int VAR>
 static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
-                      pmx_record_t *d_out, hipStream_t stream, const int *n_dev = nullptr)
+                      pmx_record_t *d_out, hipStream_t stream, const int *n_dev = nullptr, uint32_t *tbuf = nullptr, int Tmax = 0)
 {
     constexpr bool PT = VAR == 6;
-    constexpr int EB = (VAR == 3 || VAR == 5 || PT) ? 1 : 2, WR = 4 / EB, RS = (R + WR - 1) / WR * WR;
+    constexpr int EB = (VAR == 3 || VAR == 5 || VAR == 7 || PT) ? 1 : 2, WR = 4 / EB, RS = (R + WR - 1) / WR * WR;
     constexpr int QP = G * RS, NP = 2 * (64 / G);
     if (NP * m.msize > 255) return 1;                 // per-pair pad symbol must fit a byte
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
@@ -500,7 +530,7 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
     hipLaunchKernelGGL((pmx_sw16_kernel<G, R, VAR>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                        m.msize, open, ext, RP, b.q_shared, M3_LIMIT(m.max) - (VAR >= 4 ? (b.max_rlen + 2 * G + 4) * ext : 0), b.perm,
-                       n_dev, b.retry_list, b.retry_count, b.sat_above > 0 ? b.sat_above : 2147483647, d_out);
+                       n_dev, b.retry_list, b.retry_count, b.sat_above > 0 ? b.sat_above : 2147483647, tbuf, Tmax, d_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e;
     if (PT) {
@@ -511,6 +541,45 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
         return launch_one<G, R, 5>(r, m, open, ext, d_out, stream, b.retry_count);
     }
     return 0;
+}
+
+// Local alignment with traceback (batch CIGARs): the skewed byte-profile variant + packed trace output, shapes with
+// 16 rows per lane; eligible exactly when that variant would be chosen for scores (so no re-run flag can occur).
+static bool sw16_trace_ok(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext)
+{
+    if (getenv("PMX_TRACE16_GEN1") || getenv("PMX_SW16_NO_SKEW") || getenv("PMX_SW16_NO_U8") || getenv("PMX_SW16_VARIANT")) return false;
+    if (m.msize > PMX_MAX_FAST_MSIZE || open < ext || ext < 0 || open > 1024 || b.max_rlen > 30000 || b.q_shared || b.perm) return false;
+    if (m.min < -1024 || m.max > 2048 || m.min + open < 0 || open + ext > 1024 || m.max + open > 255) return false;
+    const long long feasible = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0);
+    return feasible + M3_BIAS < (long long)M3_LIMIT(m.max) - (long long)(b.max_rlen + 2 * 64 + 4) * ext;
+}
+int pmx_sw16_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, int *variant, int *Tmax, size_t *trace_bytes)
+{
+    if (!sw16_trace_ok(b, m, open, ext)) return 1;
+    int G = 0;
+    for (int v = 0; v < 4 && !G; ++v) {                  // the first shape that holds the query, whose per-pair pad symbols fit a
+        const int g = 8 << v, np = 2 * (64 / g);         // byte and whose profiles fit the LDS (the launcher's own conditions)
+        const size_t lds = (size_t)np * m.msize * g * 16 + (size_t)g * 16 + (size_t)np * (b.max_rlen + 2 * g + 12) +
+                           (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)np * 40 + 32;
+        if (b.max_qlen <= g * 16 && np * m.msize <= 255 && lds <= 160 * 1024) { *variant = v; G = g; }
+    }
+    if (!G) return 1;
+    const int NP = 2 * (64 / G);
+    *Tmax = b.max_rlen + G - 1;
+    *trace_bytes = (size_t)((b.n + NP - 1) / NP) * (size_t)*Tmax * 64 * 16;
+    return 0;
+}
+int pmx_launch_sw16_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
+                          pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream)
+{
+    if (!sw16_trace_ok(b, m, open, ext)) return 1;
+    switch (variant) {
+    case 0: return launch_one<8, 16, 7>(b, m, open, ext, d_out, stream, nullptr, tbuf, Tmax);
+    case 1: return launch_one<16, 16, 7>(b, m, open, ext, d_out, stream, nullptr, tbuf, Tmax);
+    case 2: return launch_one<32, 16, 7>(b, m, open, ext, d_out, stream, nullptr, tbuf, Tmax);
+    case 3: return launch_one<64, 16, 7>(b, m, open, ext, d_out, stream, nullptr, tbuf, Tmax);
+    }
+    return 1;
 }
 
 int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,

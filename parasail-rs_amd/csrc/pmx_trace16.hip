@@ -312,6 +312,7 @@ template <int G, int R, bool PACKED>
 __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
                                   long long n, const uint8_t *mapper, const int16_t *scores, int msize, int open, int ext,
                                   int mode, int Tmax, int stage /* LDS bytes reserved for each of the block's queries / references, 0 = none */,
+                                  int top_aligned /* query rows start at the first lane's first register (local kernel) */,
                                   const uint32_t *tbuf, const pmx_record_t *recs,
                                   uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg)
 {
@@ -341,7 +342,7 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
     const unsigned char *sq = w_lds + (qb - qlo), *sr = w_lds + stage + (rb - rlo);
     const long long block = pair / NP; const int slot = (int)(pair % NP);
     const uint32_t *tb = tbuf + (size_t)block * Tmax * (64 * TW);
-    const int P = QP - ql;
+    const int P = top_aligned ? 0 : QP - ql;
     auto ldw = [&](int i, int j) -> uint32_t {         // the trace word holding cell (i, j); 0 outside i >= -1, j >= 0
         if (i < -1 || j < 0) return 0u;
         const int er = i + P, g = er / R, k = er % R;
@@ -426,7 +427,7 @@ static int launch_trace(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     const int stage = walk_stage_bytes(b);
     { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_walk16_kernel<G, R, false>), 128 * 1024); if (rc) return rc; }
     hipLaunchKernelGGL((pmx_walk16_kernel<G, R, false>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 2 * (size_t)stage, stream,
-                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage,
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage, 0,
                        (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
@@ -444,6 +445,10 @@ int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int ope
     if (b.max_rlen > 30000 || b.q_shared) return 1;
     if (!getenv("PMX_TRACE16_GEN1") && pmx_nwsgv_trace_plan(b, m, mode, open, ext, variant, Tmax, trace_bytes) == 0) {
         *variant += 10;            // packed traceback of the second-generation nw/sg kernel
+        return 0;
+    }
+    if (mode == PMX_MODE_SW && pmx_sw16_trace_plan(b, m, open, ext, variant, Tmax, trace_bytes) == 0) {
+        *variant += 20;            // packed traceback of the local kernel
         return 0;
     }
     const long long lo = mode == PMX_MODE_SW ? -(2LL * open + 2LL * ext + (m.min < 0 ? -m.min : 0))
@@ -468,14 +473,16 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
 {
     const bool sw = mode == PMX_MODE_SW;
     if (variant >= 10) {
-        int rc = pmx_launch_nwsgv_trace(variant - 10, b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, stream);
+        const int top = variant >= 20 ? 1 : 0;
+        int rc = top ? pmx_launch_sw16_trace(variant - 20, b, m, open, ext, d_out, tbuf, Tmax, stream)
+                     : pmx_launch_nwsgv_trace(variant - 10, b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, stream);
         if (rc) return rc;
         const int stage = walk_stage_bytes(b);
 #define WALKP(GG) { const int rca = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_walk16_kernel<GG, 16, true>), 128 * 1024); if (rca) return rca; } \
                   hipLaunchKernelGGL((pmx_walk16_kernel<GG, 16, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 2 * (size_t)stage, stream, \
-                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage,     \
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage, top,     \
                        (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg)
-        switch (variant - 10) {
+        switch (variant % 10) {
         case 0: WALKP(8); break;
         case 1: WALKP(16); break;
         case 2: WALKP(32); break;

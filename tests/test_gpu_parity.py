@@ -796,6 +796,31 @@ def test_trace16_cigar_local(pkg, orc, gaps):
     q2 = random_seqs(rng, 10, 300, 1000)
     r2 = [mutate(rng, q, 0.1, 0.03) for q in q2]
     _cigar_case(pkg, orc, 2, None, q2, r2, gaps[0], gaps[1], pm, om)
+    if gaps == (5, 2):
+        assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_sw16_kernel/packed trace")
+
+
+def test_cigar_short_queries_long_references(pkg, orc):
+    """traceback shapes are picked by LDS footprint too: short queries against long references move to wider lane groups"""
+    rng = np.random.default_rng(4340)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 24, 40, 120)
+    rs = [random_seqs(rng, 1, 3000, 9000)[0] + mutate(rng, q, 0.08, 0.03) + random_seqs(rng, 1, 1000, 3000)[0] for q in qs]
+    for mode, sg, ext in ((2, None, 2), (1, None, 1), (1, orc.S2_BEG | orc.S2_END, 1)):   # (ext 2 would leave the 16-bit window in sg)
+        _cigar_case(pkg, orc, mode, sg, qs, rs, 5, ext, pm, om)
+        assert "packed trace" in pkg.lib.pmx_last_kernel().decode()
+
+
+def test_trace16_first_generation_kernels(pkg, orc, monkeypatch):
+    """the unpacked traceback kernel stays in use outside the second generation's window (forced here)"""
+    monkeypatch.setenv("PMX_TRACE16_GEN1", "1")
+    rng = np.random.default_rng(4350)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 120, 1, 250)
+    rs = [mutate(rng, q, 0.12, 0.06) if i % 3 else random_seqs(rng, 1, 1, 300)[0] for i, q in enumerate(qs)]
+    for mode, sg in ((2, None), (1, None), (0, None), (1, orc.S1_BEG | orc.S2_END)):
+        _cigar_case(pkg, orc, mode, sg, qs, rs, 5, 2, pm, om)
+    assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_trace16_kernel")
 
 
 def test_batch_cigar_chunking(pkg, orc, monkeypatch):
