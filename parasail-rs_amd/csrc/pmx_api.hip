@@ -1053,6 +1053,38 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         }
         // rc == 1: shape not covered by the fast kernel -> general kernel below
     }
+    if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&
+        dm.d.msize <= 8 && !q_shared && !getenv("PMX_NO_STATS_BY_TRACE")) {
+        // Small alphabets: statistics = counts along the traceback path (the same decisions and tie-breaks as the
+        // coupled statistics tables).  The packed traceback sweep runs at more than twice the speed of the
+        // statistics kernel and the walk is cheap; the trace scratch is bounded by working in chunks (same stream,
+        // no host synchronisation).  Large alphabets keep the statistics kernel: their LDS profiles would starve
+        // the 16-rows-per-lane traceback shapes of occupancy.
+        PmxBatch bt = b; bt.perm = nullptr;
+        int variant = 0, Tmax = 0; size_t tbytes = 0;
+        if (pmx_trace16_plan(bt, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes) == 0 && variant >= 10) {
+            double budget = 8e9;
+            { size_t fb = 0, tb = 0; if (hipMemGetInfo(&fb, &tb) == hipSuccess && 0.3 * (double)fb < budget) budget = 0.3 * (double)fb; }
+            const double per_pair = (double)tbytes / (double)n + 1.0;
+            int64_t chunk = (int64_t)(budget / per_pair) / 64 * 64;
+            if (chunk < 64) chunk = 64;
+            if (chunk > n) chunk = n;
+            bt.n = chunk;
+            (void)pmx_trace16_plan(bt, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes);
+            uint32_t *tbuf = nullptr;
+            if (scratch_reserve(tbytes, (void **)&tbuf, SCR_TRACE)) return -1;
+            for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+                PmxBatch bc = bt;
+                bc.n = (n - c0 < chunk) ? n - c0 : chunk;
+                bc.qoff = d_qoff + c0; bc.roff = d_roff + c0;
+                const int rc = pmx_launch_trace16(variant, bc, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out + c0, tbuf, Tmax,
+                                                  nullptr, nullptr, nullptr, nullptr, st, d_stats_out + c0);
+                if (rc) { set_err("stats-by-traceback launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+            }
+            g_last_kernel = variant >= 20 ? "pmx_sw16_kernel/packed trace + pmx_walk16_kernel/stats" : "pmx_nwsg16v_kernel/packed trace + pmx_walk16_kernel/stats";
+            return 0;
+        }
+    }
     if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
         const int rc = pmx_launch_stats16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, d_stats_out, st, &g_last_kernel);
         if (rc < 0) { set_err("stats16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }

@@ -67,7 +67,8 @@ int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int ope
                      int *variant, int *Tmax, size_t *trace_bytes);
 int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                        pmx_record_t *d_out, uint32_t *tbuf, int Tmax,
-                       uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream);
+                       uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream,
+                       pmx_stats_t *stats_out = nullptr /* count the path's statistics instead of emitting ops */);
 
 // ---- general kernel (all modes, stats, tables, rows/cols, trace, band) -------------------
 struct PmxGeneralArgs {

@@ -313,6 +313,8 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
                                   long long n, const uint8_t *mapper, const int16_t *scores, int msize, int open, int ext,
                                   int mode, int Tmax, int stage /* LDS bytes reserved for each of the block's queries / references, 0 = none */,
                                   int top_aligned /* query rows start at the first lane's first register (local kernel) */,
+                                  pmx_stats_t *stats_out /* != nullptr: count matches / similar / length along the path instead of emitting ops */,
+                                  int row_pen, int col_pen /* stats: the begin gaps along the reference / query are part of the alignment */,
                                   const uint32_t *tbuf, const pmx_record_t *recs,
                                   uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg)
 {
@@ -351,15 +353,18 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
     };
     auto nibof = [&](uint32_t w, int i) -> unsigned { return (w >> (28 - 4 * (((i + P) % R) % 8))) & 0xFu; };
     auto nib = [&](int i, int j) -> unsigned { return nibof(ldw(i, j), i); };
-    uint32_t *o = ops + ops_off[pair];
+    const bool st = stats_out != nullptr;
+    uint32_t *o = st ? nullptr : ops + ops_off[pair];
     const pmx_record_t rec = recs[pair];
     int i = rec.end_query, j = rec.end_ref, cnt = 0;
     uint32_t cur_op = 0, cur_len = 0;
+    int nM = 0, nS = 0, nL = 0;      // statistics of the path = the coupled stats tables of the reference (same decisions, same ties)
     auto emit = [&](uint32_t op) {
+        if (st) { ++nL; return; }
         if (op == cur_op) ++cur_len;
         else { if (cur_len) o[cnt++] = (cur_len << 4) | cur_op; cur_op = op; cur_len = 1; }
     };
-    if (mode == PMX_MODE_SG) {
+    if (mode == PMX_MODE_SG && !st) {
         if (i + 1 == ql) { for (int k = rl - 1; k > j; --k) emit(OP_FOR_INS_STATE); }
         else if (j + 1 == rl) { for (int k = ql - 1; k > i; --k) emit(OP_FOR_DEL_STATE); }
     }
@@ -367,14 +372,15 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
     const bool sw = mode == PMX_MODE_SW;
     int rem = rec.score;       // local alignment: value of the current H / E / F cell; the path starts where it is used up
     while (i >= 0 || j >= 0) {
-        if (i < 0) { if (sw) break; emit(OP_FOR_INS_STATE); --j; continue; }
-        if (j < 0) { if (sw) break; emit(OP_FOR_DEL_STATE); --i; continue; }
+        if (i < 0) { if (sw || (st && !row_pen)) break; emit(OP_FOR_INS_STATE); --j; continue; }
+        if (j < 0) { if (sw || (st && !col_pen)) break; emit(OP_FOR_DEL_STATE); --i; continue; }
         if (where == 0) {
             if (sw && rem <= 0) break;                       // ZERO cell
             const unsigned t = nib(i, j);
             if (!(t & 8u)) {
                 const int a = s_map[stage ? sq[i] : q[i]], b = s_map[stage ? sr[j] : r[j]];
                 emit(a == b ? OP_EQ : OP_X);
+                if (st) { nM += a == b; nS += s_scores[a * msize + b] > 0; }
                 if (sw) rem -= s_scores[a * msize + b];
                 --i; --j;
             }
@@ -390,6 +396,7 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
             --i;
         }
     }
+    if (st) { pmx_stats_t r3; r3.matches = nM; r3.similar = nS; r3.length = nL; stats_out[pair] = r3; return; }
     if (cur_len) o[cnt++] = (cur_len << 4) | cur_op;
     for (int k = 0; k < cnt / 2; ++k) { const uint32_t tmp = o[k]; o[k] = o[cnt - 1 - k]; o[cnt - 1 - k] = tmp; }
     nops[pair] = cnt;
@@ -407,7 +414,7 @@ static int walk_stage_bytes(const PmxBatch &b)
 template <int G, int R, bool SW>
 static int launch_trace(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                         pmx_record_t *d_out, uint32_t *tbuf, int Tmax,
-                        uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream)
+                        uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, pmx_stats_t *stats_out, hipStream_t stream)
 {
     constexpr int QP = G * R, NP = 64 / G;
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
@@ -427,7 +434,7 @@ static int launch_trace(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     const int stage = walk_stage_bytes(b);
     { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_walk16_kernel<G, R, false>), 128 * 1024); if (rc) return rc; }
     hipLaunchKernelGGL((pmx_walk16_kernel<G, R, false>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 2 * (size_t)stage, stream,
-                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage, 0,
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage, 0, stats_out, row_pen, col_pen,
                        (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
@@ -469,9 +476,11 @@ int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int ope
 
 int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                        pmx_record_t *d_out, uint32_t *tbuf, int Tmax,
-                       uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream)
+                       uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream, pmx_stats_t *stats_out)
 {
     const bool sw = mode == PMX_MODE_SW;
+    const bool sg_ = mode == PMX_MODE_SG;
+    const int col_pen_ = sw ? 0 : !(sg_ && (sg_flags & PMX_SG_QB)), row_pen_ = sw ? 0 : !(sg_ && (sg_flags & PMX_SG_DB));
     if (variant >= 10) {
         const int top = variant >= 20 ? 1 : 0;
         int rc = top ? pmx_launch_sw16_trace(variant - 20, b, m, open, ext, d_out, tbuf, Tmax, stream)
@@ -480,7 +489,7 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
         const int stage = walk_stage_bytes(b);
 #define WALKP(GG) { const int rca = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_walk16_kernel<GG, 16, true>), 128 * 1024); if (rca) return rca; } \
                   hipLaunchKernelGGL((pmx_walk16_kernel<GG, 16, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 2 * (size_t)stage, stream, \
-                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage, top,     \
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage, top, stats_out, row_pen_, col_pen_,     \
                        (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg)
         switch (variant % 10) {
         case 0: WALKP(8); break;
@@ -492,8 +501,8 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : -(int)e;
     }
-#define LT(GG, RR) (sw ? launch_trace<GG, RR, true>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stream) \
-                       : launch_trace<GG, RR, false>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stream))
+#define LT(GG, RR) (sw ? launch_trace<GG, RR, true>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stats_out, stream) \
+                       : launch_trace<GG, RR, false>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stats_out, stream))
     switch (variant) {
     case 0: return LT(32, 8);
     case 1: return LT(64, 8);

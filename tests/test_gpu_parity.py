@@ -690,7 +690,10 @@ def _stats_case(pkg, orc, mode, sg, qs, rs, open_, ext, pm, om, shared_query=Non
 
 
 @pytest.mark.parametrize("gaps", [(5, 2), (1, 1), (11, 1), (3, 3)])
-def test_stats16_gap_models(pkg, orc, gaps):
+@pytest.mark.parametrize("by_trace", [True, False])
+def test_stats16_gap_models(pkg, orc, gaps, monkeypatch, by_trace):
+    if not by_trace:
+        monkeypatch.setenv("PMX_NO_STATS_BY_TRACE", "1")       # the statistics kernel itself (what large alphabets use)
     rng = np.random.default_rng(5000 + gaps[0])
     pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
     qs = random_seqs(rng, 300, 1, 160)          # ragged and >= 256 pairs: also exercises the length-sorted order
@@ -700,7 +703,10 @@ def test_stats16_gap_models(pkg, orc, gaps):
 
 
 @pytest.mark.parametrize("gaps", [(5, 2), (1, 1), (11, 1)])
-def test_stats16_local(pkg, orc, gaps):
+@pytest.mark.parametrize("by_trace", [True, False])
+def test_stats16_local(pkg, orc, gaps, monkeypatch, by_trace):
+    if not by_trace:
+        monkeypatch.setenv("PMX_NO_STATS_BY_TRACE", "1")       # the statistics kernel itself (what large alphabets use)
     rng = np.random.default_rng(5050 + gaps[0])
     pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
     qs = random_seqs(rng, 300, 1, 160)
@@ -714,7 +720,10 @@ def test_stats16_local(pkg, orc, gaps):
     _stats_case(pkg, orc, 2, None, None, rs2, 11, 1, b62, ob62, shared_query=q)
 
 
-def test_stats16_sg_variants_and_sizes(pkg, orc):
+@pytest.mark.parametrize("by_trace", [True, False])
+def test_stats16_sg_variants_and_sizes(pkg, orc, monkeypatch, by_trace):
+    if not by_trace:
+        monkeypatch.setenv("PMX_NO_STATS_BY_TRACE", "1")       # the statistics kernel itself (what large alphabets use)
     rng = np.random.default_rng(5100)
     pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
     qs = random_seqs(rng, 60, 20, 150)
