@@ -1054,7 +1054,8 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         // rc == 1: shape not covered by the fast kernel -> general kernel below
     }
     if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&
-        dm.d.msize <= 8 && !q_shared && !getenv("PMX_NO_STATS_BY_TRACE")) {
+        dm.d.msize <= 8 && !q_shared && (n >= 2048 || getenv("PMX_STATS_BY_TRACE")) && !getenv("PMX_NO_STATS_BY_TRACE")) {
+        // (a few pairs: the one-pass statistics kernel has the lower latency)
         // Small alphabets: statistics = counts along the traceback path (the same decisions and tie-breaks as the
         // coupled statistics tables).  The packed traceback sweep runs at more than twice the speed of the
         // statistics kernel and the walk is cheap; the trace scratch is bounded by working in chunks (same stream,

@@ -692,8 +692,8 @@ def _stats_case(pkg, orc, mode, sg, qs, rs, open_, ext, pm, om, shared_query=Non
 @pytest.mark.parametrize("gaps", [(5, 2), (1, 1), (11, 1), (3, 3)])
 @pytest.mark.parametrize("by_trace", [True, False])
 def test_stats16_gap_models(pkg, orc, gaps, monkeypatch, by_trace):
-    if not by_trace:
-        monkeypatch.setenv("PMX_NO_STATS_BY_TRACE", "1")       # the statistics kernel itself (what large alphabets use)
+    # small alphabets: statistics by traceback for >= 2048 pairs (forced here), the statistics kernel otherwise
+    monkeypatch.setenv("PMX_STATS_BY_TRACE" if by_trace else "PMX_NO_STATS_BY_TRACE", "1")
     rng = np.random.default_rng(5000 + gaps[0])
     pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
     qs = random_seqs(rng, 300, 1, 160)          # ragged and >= 256 pairs: also exercises the length-sorted order
@@ -705,8 +705,8 @@ def test_stats16_gap_models(pkg, orc, gaps, monkeypatch, by_trace):
 @pytest.mark.parametrize("gaps", [(5, 2), (1, 1), (11, 1)])
 @pytest.mark.parametrize("by_trace", [True, False])
 def test_stats16_local(pkg, orc, gaps, monkeypatch, by_trace):
-    if not by_trace:
-        monkeypatch.setenv("PMX_NO_STATS_BY_TRACE", "1")       # the statistics kernel itself (what large alphabets use)
+    # small alphabets: statistics by traceback for >= 2048 pairs (forced here), the statistics kernel otherwise
+    monkeypatch.setenv("PMX_STATS_BY_TRACE" if by_trace else "PMX_NO_STATS_BY_TRACE", "1")
     rng = np.random.default_rng(5050 + gaps[0])
     pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
     qs = random_seqs(rng, 300, 1, 160)
@@ -722,8 +722,8 @@ def test_stats16_local(pkg, orc, gaps, monkeypatch, by_trace):
 
 @pytest.mark.parametrize("by_trace", [True, False])
 def test_stats16_sg_variants_and_sizes(pkg, orc, monkeypatch, by_trace):
-    if not by_trace:
-        monkeypatch.setenv("PMX_NO_STATS_BY_TRACE", "1")       # the statistics kernel itself (what large alphabets use)
+    # small alphabets: statistics by traceback for >= 2048 pairs (forced here), the statistics kernel otherwise
+    monkeypatch.setenv("PMX_STATS_BY_TRACE" if by_trace else "PMX_NO_STATS_BY_TRACE", "1")
     rng = np.random.default_rng(5100)
     pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
     qs = random_seqs(rng, 60, 20, 150)
