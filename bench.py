@@ -285,6 +285,15 @@ def main():
                               "model": "per 128 cells: 5.5 VOP3/VOP3P x 4 cycles + 3 VOP2 x 2 cycles = 28 SIMD cycles; "
                                        "1024 SIMDs x 2.4 GHz (measured issue rates, profiles/r01)"},
         }
+        if world == 1 and not multi and n == N_PAIRS:
+            # the same batch handed over in host memory (H2D + kernels + D2H inside): reported beside, never as `value`
+            al = pkg.Aligner.new().local().matrix(matrix).gap_open(OPEN).gap_extend(EXT).solution_width(16).build()
+            al.align_batch_packed(qbuf, qoff, rbuf, roff)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter(); al.align_batch_packed(qbuf, qoff, rbuf, roff); ts.append(time.perf_counter() - t0)
+            line["pcie_inclusive"] = {"value": round(cells_per_rank_step / min(ts) / 1e9, 1), "unit": "GCUPS",
+                                      "ms": round(min(ts) * 1e3, 3), "entry": "pmx_align_batch (pageable host buffers)"}
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_out = cpu_baseline(qbuf, qoff, rbuf, roff)
             line["cpu_baseline"] = cb
