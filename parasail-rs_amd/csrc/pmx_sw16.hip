@@ -1,8 +1,8 @@
 // pmx_sw16.hip -- the hot kernel: local (Smith-Waterman) affine-gap alignment, score and
 // end positions, many independent pairs per launch.  gfx950 only.
 //
-// Replaces what `Aligner::align()` reaches for the dispatch names `sw_striped_16` /
-// `sw_striped_sat` (name grammar /root/reference/src/aligner/mod.rs:319-329, call site
+// Replaces what `Aligner::align()` reaches for the dispatch names `sw_striped_{8,16,32,64,sat}`
+// (and, with traceback, `sw_trace_striped_*` in batches) (name grammar /root/reference/src/aligner/mod.rs:319-329, call site
 // :411-422): the parasail CPU kernel fills the DP matrix column by column with 8/16 SIMD
 // lanes striped over the query.  Here the mapping is re-designed for a 64-lane wavefront:
 //
@@ -17,10 +17,17 @@
 //   * The per-pair query profile (score of every query row against every reference symbol,
 //     int16) is built in LDS once; per step a lane fetches the R scores of its rows for the
 //     current reference symbol of pair A and of pair B and interleaves them with v_perm_b32.
-//   * H lives in an offset domain (value - 32768): v_pk_add_i16 with clamp then saturates at
-//     "zero" for free, which removes the max(.,0) of local alignment, and gives an exact range
-//     of 0..65535 so that int16 overflow (score > 32767) can be reported like the reference's
-//     `is_saturated` (src/alignment/mod.rs:436-440).
+//   * Arithmetic variants (template parameter VAR, chosen by the host, all bit-identical in result):
+//       0  saturating int16 in an offset domain (value - 32768): the clamp of v_pk_add_i16 is the zero
+//          floor of local alignment, and int16 overflow (score > 32767) is detected exactly, like the
+//          reference's `is_saturated` (src/alignment/mod.rs:436-440);
+//       1  + v_pk_maximum3_f16 as an exact integer max3 on biased values;
+//       2  + 32-bit VOP2 add/sub (profile carries score + open, strips carry H - open);
+//       3  + one-byte profile entries;
+//       4/5  + column-skewed values (no subtract for the E extension), int16 / byte profile;
+//       6  + perm table: no LDS profile at all for alphabets of <= 4 letters (the hot configuration);
+//       7  = 5 + packed 4-bit traceback output for batch CIGARs.
+//     DESIGN.md section 2.1 has the derivations; the comments at each `constexpr bool` below the details.
 //   * End position = first maximum in column-major order (smallest end_ref, then smallest
 //     end_query): each lane keeps its running best, the column where it was first reached and a
 //     copy of its R-row H strip at that column (v_bfi_b32 under a per-half mask); a group
