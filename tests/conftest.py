@@ -21,6 +21,12 @@ def orc():
 
 @pytest.fixture(scope="session")
 def pkg():
+    # torch ships its own HIP runtime: when a test uses both (device tensors handed to the C ABI, as bench.py does),
+    # torch's copy has to be the one that is loaded first, or torch finds no GPU afterwards
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     import __graft_entry__ as g
     if not os.path.exists(os.path.join(g.PKG_DIR, "lib", "libparasail_amd.so")):
         g.build()

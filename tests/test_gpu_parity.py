@@ -1009,3 +1009,32 @@ def test_headline_config_properties(pkg, orc):
     # deterministic
     again = al.align_batch_packed(qbuf, qoff, rbuf, roff)
     assert (again == got).all()
+
+
+def test_host_entry_pipelined_slices_with_mixed_lengths(pkg, orc):
+    """pmx_align_batch sends large batches up in slices that overlap the kernels; every pair of a 300k batch with
+    mixed (not sorted-worthy) lengths against the striped CPU port, and against the one-shot device path"""
+    import torch
+    rng = np.random.default_rng(6100)
+    n = 300_000
+    ql = rng.integers(125, 151, size=n); rl = rng.integers(125, 151, size=n)
+    qoff = np.zeros(n + 1, dtype=np.int64); np.cumsum(ql, out=qoff[1:])
+    roff = np.zeros(n + 1, dtype=np.int64); np.cumsum(rl, out=roff[1:])
+    qbuf = DNA[rng.integers(0, 4, size=int(qoff[-1]))]
+    rbuf = DNA[rng.integers(0, 4, size=int(roff[-1]))]
+    for k in range(0, n, 1000):                       # some wildcards: the perm-table kernel's retry path inside slices
+        qbuf[qoff[k] + 3] = ord("N")
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    al = pkg.Aligner.new().local().matrix(pm).gap_open(5).gap_extend(2).solution_width(16).build()
+    got = al.align_batch_packed(qbuf, qoff, rbuf, roff)
+    want, _ = orc.cpu_sw_striped16_batch(qbuf, qoff, rbuf, roff, 5, 2, om)
+    assert (got["score"] == want[:, 0]).all() and (got["end_query"] == want[:, 1]).all() and (got["end_ref"] == want[:, 2]).all()
+    assert (got["flags"] == 0).all()
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(x).to(dev) for x in (qbuf, qoff, rbuf, roff)]
+    out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    pkg.align_batch_device(al._config(), n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 150, 150,
+                           out.data_ptr(), None, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert (o[:, 0] == got["score"]).all() and (o[:, 1] == got["end_query"]).all() and (o[:, 2] == got["end_ref"]).all()
