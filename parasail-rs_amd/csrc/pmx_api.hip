@@ -1251,6 +1251,22 @@ extern "C" int pmx_align_profile_batch_device(const pmx_config_t *cfg, const par
                             d_out, d_stats_out, stream, profile_has_wildcard(profile));
 }
 
+// The caller-owned CIGAR text: a malloc block that grows chunk by chunk; device text is copied straight into it.
+struct TextBuf {
+    char *p = nullptr; size_t len = 0, cap = 0;
+    char *grow(size_t extra)       // room for `extra` more bytes (+ terminator); returns the write position or nullptr
+    {
+        if (len + extra + 1 > cap) {
+            size_t ncap = cap ? cap * 2 : 4096;
+            while (ncap < len + extra + 1) ncap *= 2;
+            char *np = (char *)realloc(p, ncap);
+            if (!np) return nullptr;
+            p = np; cap = ncap;
+        }
+        return p + len;
+    }
+};
+
 // CIGAR for a batch.  Fast path: pmx_trace16 (4-bit trace in HBM, on-device walk); otherwise the general
 // kernel with byte trace tables and pmx_walk_kernel.  Only the run-length ops come back to the host, which
 // renders the text.  One chunk = one set of launches; chunks bound the trace scratch.
@@ -1264,7 +1280,7 @@ struct StageTimer {
 
 static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
                        const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
-                       pmx_record_t *out, std::string &text, int64_t *cigar_off /* n+1, cigar_off[0] preset */)
+                       pmx_record_t *out, TextBuf &text, int64_t *cigar_off /* n+1, cigar_off[0] preset */)
 {
     StageTimer tm;
     int32_t mq = 0, mr = 0; bool bad = false;
@@ -1343,9 +1359,11 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
     HIP_OR_RET(hipMemcpy(dtoff.p, toff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     rc = pmx_launch_cigar_render(dops, doo.p, dnops.p, dtoff.p, dtext.p, n, nullptr);
     if (rc) { set_err("cigar render kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
-    const size_t base = text.size();
-    text.resize(base + (size_t)toff[n]);
-    if (toff[n]) HIP_OR_RET(hipMemcpy(&text[base], dtext.p, (size_t)toff[n], hipMemcpyDeviceToHost));
+    const size_t base = text.len;
+    char *dst = text.grow((size_t)toff[n]);
+    if (!dst) { set_err("out of memory"); return -1; }
+    if (toff[n]) HIP_OR_RET(hipMemcpy(dst, dtext.p, (size_t)toff[n], hipMemcpyDeviceToHost));
+    text.len += (size_t)toff[n];
     for (int64_t k = 0; k < n; ++k) cigar_off[k + 1] = (int64_t)base + toff[k + 1];
     tm.done("render + D2H");
     return 0;
@@ -1364,7 +1382,7 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
     if (qoff[0] != 0 || roff[0] != 0) { set_err("offset arrays must start at 0"); return -1; }
     DevMat dm;
     if (get_devmat(cfg->matrix, &dm)) return -1;
-    std::string text;
+    TextBuf text;
     cigar_off[0] = 0;
     // Chunks bound the per-launch trace scratch: budgeted at one byte per cell of the padded tables (the
     // general kernel's layout; the fast kernels write 4 bits per cell).  Large chunks matter: the walk is one
@@ -1393,12 +1411,12 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
         for (int64_t k = 0; k <= m; ++k) { qo[k] = qoff[c0 + k] - qoff[c0]; ro[k] = roff[c0 + k] - roff[c0]; }
         const int rc = cigar_chunk(cfg, dm, m, qbuf + qoff[c0], qo.data(), rbuf + roff[c0], ro.data(),
                                    out + c0, text, cigar_off + c0);
-        if (rc) return rc;
+        if (rc) { free(text.p); return rc; }
         c0 = c1;
     }
-    *cigar_buf = (char *)malloc(text.size() + 1);
-    if (!*cigar_buf) { set_err("out of memory"); return -1; }
-    memcpy(*cigar_buf, text.c_str(), text.size() + 1);
+    if (!text.grow(0)) { set_err("out of memory"); return -1; }
+    text.p[text.len] = 0;
+    *cigar_buf = text.p;
     return 0;
 }
 
