@@ -286,7 +286,6 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     const v2s vOpen = PK((open & 0xFFFF) | (open << 16));
     const v2s vExt = PK((ext & 0xFFFF) | (ext << 16));
     typedef unsigned short v2u __attribute__((ext_vector_type(2)));
-    const v2u one2 = {1, 1};
     // "zero" of the value domain: -32768 for the saturating-int16 variant, BIAS for the max3 variant
     constexpr int ZERO2 = M3 ? M3_BIAS2 : FLOOR2;
     const v2s vZero = PK(ZERO2);
@@ -306,8 +305,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 #pragma unroll
     for (int k = 0; k < R; ++k) { HA[k] = vInitH; HB[k] = vInitH; E[k] = V2 ? vInitH : (M3 ? PK(0) : vZero); Hsave[k] = vZero; }
     v2s best = PK(ZERO2 + skew0 - (SK ? I32(vC) : 0));     // SK: X form
-    int bestcol = 0;
-    int jj = ((-g) & 0xFFFF) * 0x00010001;    // packed column index of this lane
+    int bestcol = g * 0x00010001;             // STEP at which the best was first exceeded (column = step - g; initially column 0)
     int Zv = ZERO2 + skew0 + I32(vExt);       // SK: "F^ = 0" of the current column; += ext per step
     const int HNEUTRAL = V2 ? ZERO2 - I32(vOpen) : ZERO2;
     // last-row H (V2: H - open) and outgoing F of the previous step; SK: what lane g+1 reads at step 0
@@ -376,7 +374,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                 // the column maximum, the running best and the saved strip all live in the X form (H~ - (open - ext)):
                 // the strip itself is what gets saved, no second copy of the column is kept in registers
                 if (k & 1) colmax = pk_max3f(colmax, Hnew[k - 1], X);
-                else if (k == R - 1) colmax = pk_max3f(colmax, X, X);
+                else if (k == R - 1) colmax = pk_max3f(colmax, X, best);      // odd R: the spare operand folds the running best in
             } else if (V2) {
                 // Same domain as the max3 variant, but the strips carry H - open and the profile
                 // carries score + open (>= 0), so add and subtract never carry or borrow across
@@ -425,15 +423,16 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         Hout = I32(Hnew[R - 1]);
         Fout = I32(F);
         // end-position bookkeeping: strictly greater than the lane's best so far?
-        const v2s nb = M3 ? pk_max3f(best, colmax, colmax) : pk_max(best, colmax);
+        constexpr bool FOLDED = SK && (R & 1);          // colmax already holds max(best, column maximum)
+        const v2s nb = FOLDED ? colmax : M3 ? pk_max3f(best, colmax, colmax) : pk_max(best, colmax);
         int m;   // 0xFFFF in every half whose column maximum strictly exceeds the best so far
         {
-            const v2s dd = M3 ? (best - colmax) : pk_subs(best, colmax);   // negative exactly where colmax > best
+            const v2s dd = FOLDED ? (best - nb) : M3 ? (best - colmax) : pk_subs(best, colmax);   // negative exactly where colmax > best
             const v2s sh = {15, 15};
             m = I32(dd >> sh);                              // v_pk_ashrrev_i16
         }
         // v_bfi_b32 d = (m & a) | (~m & b)
-        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bestcol) : "v"(m), "v"(jj), "v"(bestcol));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bestcol) : "v"(m), "s"((t & 0xFFFF) * 0x00010001), "v"(bestcol));   // the step index is uniform: SGPR operand
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             int hs;
@@ -442,7 +441,6 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         }
         best = SK ? PK(I32(nb) + I32(vExt)) : nb;                           // SK: carried into the next column's skew
         if (SK) Zv += I32(vExt);
-        jj = __builtin_bit_cast(int, __builtin_bit_cast(v2u, jj) + one2);   // per-half add: no carry into pair B
     };
 
     // software pipeline: scores of step t+1 are fetched from LDS while step t computes
@@ -468,9 +466,10 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     unsigned long long keyA, keyB;
     {
         const int bA = (short)(I32(best) & 0xFFFF), bB = (short)(I32(best) >> 16);
-        const unsigned cA = bestcol & 0xFFFF, cB = (unsigned)bestcol >> 16;
+        const unsigned stA = bestcol & 0xFFFF, stB = (unsigned)bestcol >> 16;      // save steps
+        const unsigned cA = stA - g, cB = stB - g;                                 // columns
         // SK: `best` was carried through T - (save step) columns after the strip was saved
-        const int tA = SK ? bA - (T - ((int)cA + g)) * ext : bA, tB = SK ? bB - (T - ((int)cB + g)) * ext : bB;
+        const int tA = SK ? bA - (T - (int)stA) * ext : bA, tB = SK ? bB - (T - (int)stB) * ext : bB;
         int kA = 0, kB = 0;
 #pragma unroll
         for (int k = R - 1; k >= 0; --k) {
