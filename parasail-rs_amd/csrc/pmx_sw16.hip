@@ -49,10 +49,14 @@ __device__ __forceinline__ v2s pk_subs(v2s a, v2s b) { return __builtin_elementw
 __device__ __forceinline__ v2s pk_max(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
 
 // value of lane-1 inside a G-lane group; lane 0 of the group receives `neutral`.
-template <int G>
+// IL (G == 8 only): two groups share a DPP row of 16 lanes, interleaved (lane = 2 g + (slot & 1) + 16 (slot >> 1)).
+// row_shr:2 then moves every group up by one lane, and the row's first two lanes -- lane 0 of both groups --
+// have no source and keep `neutral`: no select is needed.
+template <int G, bool IL = false>
 __device__ __forceinline__ int group_shift_up(int x, int neutral, int g)
 {
     if (G == 1) return neutral;
+    if (IL) return __builtin_amdgcn_update_dpp(neutral, x, 0x112 /*row_shr:2*/, 0xF, 0xF, false);
     if (G <= 16) {
         int r = __builtin_amdgcn_update_dpp(neutral, x, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
         if (G < 16) r = (g == 0) ? neutral : r;
@@ -122,8 +126,9 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int lane = threadIdx.x;
-    const int g = lane % G;
-    const int slot = lane / G;
+    constexpr bool IL = G == 8 && VAR != 7;     // interleaved 8-lane groups (see group_shift_up); the trace layout keeps plain groups
+    const int g = IL ? (lane % 16) / 2 : lane % G;
+    const int slot = IL ? (lane / 16) * 2 + (lane & 1) : lane / G;
     const int PROF_STRIDE = PT ? 0 : msize * QP * EB;   // bytes per pair
 
     // LDS carve: [prof NP][shared pad row QP*2][rsym NP*RP][mat msize*msize*2][map 256][pair table NP*4 ints]
@@ -329,8 +334,9 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         pl = PK(r);
     };
     auto step = [&](const v2s (&Hold)[R], v2s (&Hnew)[R], const int (&wa)[RS / WR], const int (&wb)[RS / WR], int t) {
-        const int Hin = group_shift_up<G>(Hout, SK ? Zv - I32(vOpen) : HNEUTRAL, g); // H(i0-1, j)
-        v2s F = PK(group_shift_up<G>(Fout, SK ? Zv : ZERO2, g));                       // F(i0, j)
+        const int Hin = group_shift_up<G, IL>(Hout, SK ? Zv - I32(vOpen) : HNEUTRAL, g); // H(i0-1, j)
+        const int Fin = group_shift_up<G, IL>(Fout, SK ? Zv : ZERO2, g);                  // F(i0, j)
+        v2s F = PK(Fin);
         v2s colmax = SK ? PK(0) : vZero;
         v2s Hcur[R];                                           // V2 only: this column's H (the strips hold H - open)
         v2s Tpre[R], Epre[R];                                  // V2 only: hoisted independent adds / subtracts
@@ -484,10 +490,11 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     }
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1) {
-        const unsigned long long oa = __shfl_xor(keyA, off, 64), ob = __shfl_xor(keyB, off, 64);
+        const int lo = IL ? 2 * off : off;              // lane distance of group members `off` apart
+        const unsigned long long oa = __shfl_xor(keyA, lo, 64), ob = __shfl_xor(keyB, lo, 64);
         keyA = oa > keyA ? oa : keyA;
         keyB = ob > keyB ? ob : keyB;
-        if (PT) wild |= __shfl_xor(wild, off, 64);
+        if (PT) wild |= __shfl_xor(wild, lo, 64);
     }
     if (g == 0) {
 #pragma unroll
