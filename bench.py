@@ -285,7 +285,7 @@ def main():
                               "model": "per 128 cells: 5.5 VOP3/VOP3P x 4 cycles + 3 VOP2 x 2 cycles = 28 SIMD cycles; "
                                        "1024 SIMDs x 2.4 GHz (measured issue rates, profiles/r01)"},
         }
-        if world == 1 and not multi and n == N_PAIRS:
+        if world == 1 and not multi and n == N_PAIRS and not args.no_cpu_baseline:
             # the same batch handed over in host memory (H2D + kernels + D2H inside): reported beside, never as `value`
             al = pkg.Aligner.new().local().matrix(matrix).gap_open(OPEN).gap_extend(EXT).solution_width(16).build()
             al.align_batch_packed(qbuf, qoff, rbuf, roff)
