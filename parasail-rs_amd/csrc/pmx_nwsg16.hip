@@ -79,9 +79,12 @@ __device__ __forceinline__ int m_ult(v2s a, v2s b)        // unsigned a < b (a m
     return I32(__builtin_bit_cast(v2s, zero - __builtin_elementwise_min(d, one)));
 }
 
-template <int G>
+// IL (G == 8): two groups interleaved in a DPP row of 16 lanes (lane = 2 g + (slot & 1) + 16 (slot >> 1)): row_shr:2
+// moves every group up by one lane and the row's first two lanes keep `neutral` -- no select (see pmx_sw16.hip).
+template <int G, bool IL = false>
 __device__ __forceinline__ int n_shift_up(int x, int neutral, int g)
 {
+    if (IL) return __builtin_amdgcn_update_dpp(neutral, x, 0x112 /*row_shr:2*/, 0xF, 0xF, false);
     if (G <= 16) {
         int r = __builtin_amdgcn_update_dpp(neutral, x, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
         if (G < 16) r = (g == 0) ? neutral : r;
@@ -398,8 +401,9 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int lane = threadIdx.x;
-    const int g = lane % G;
-    const int slot = lane / G;
+    constexpr bool IL = G == 8 && !TR;          // interleaved 8-lane groups; the trace layout keeps plain groups
+    const int g = IL ? (lane % 16) / 2 : lane % G;
+    const int slot = IL ? (lane / 16) * 2 + (lane & 1) : lane / G;
     const int MS1 = msize + 1;                      // + the pad-symbol row
     const int PROF_STRIDE = MS1 * QPS;
 
@@ -537,8 +541,8 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         pl = PK(r);
     };
     auto step = [&](const int (&Hold)[R], int (&Hnew)[R], const int (&wa)[RS / 4], const int (&wb)[RS / 4], int t) {
-        const int Hin = n_shift_up<G>(Hout, topX, g);
-        int F = n_shift_up<G>(Fout, topX, g);            // F^ into row 0 = X of the row above (see the header)
+        const int Hin = n_shift_up<G, IL>(Hout, topX, g);
+        int F = n_shift_up<G, IL>(Fout, topX, g);            // F^ into row 0 = X of the row above (see the header)
         int Tpre[R];
         v2s plane[TR ? R / 4 : 1];
         if (TR) {
@@ -635,11 +639,12 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     unsigned keyB = ((unsigned)((unsigned)I32(bestcol) >> 16) << 16) | (0xFFFFu - ((unsigned)bestcoli >> 16));
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1) {
-        const unsigned oa = __shfl_xor(keyA, off, 64), ob = __shfl_xor(keyB, off, 64);
+        const int lo = IL ? 2 * off : off;
+        const unsigned oa = __shfl_xor(keyA, lo, 64), ob = __shfl_xor(keyB, lo, 64);
         keyA = oa > keyA ? oa : keyA;
         keyB = ob > keyB ? ob : keyB;
     }
-    const int lastlane = slot * G + G - 1;
+    const int lastlane = IL ? 2 * (G - 1) + (slot & 1) + 16 * (slot >> 1) : slot * G + G - 1;
     const int resL = __shfl(res, lastlane, 64);
     const int browL = __shfl(I32(bestrow), lastlane, 64), browjL = __shfl(bestrowj, lastlane, 64);
     if (g == 0) {
