@@ -789,7 +789,13 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
             int rc = launch_nwsgv<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
             if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; }   \
         }
-        TRYV(8, 20, "pmx_nwsg16v_kernel<8,20>")
+        if (b.n > 2048) {       // (few pairs: latency counts, the 16-lane shapes have half the work per step)
+            TRYV(8, 13, "pmx_nwsg16v_kernel<8,13>")      // reads of 100 / 125 / 150 bp: few padding rows
+            TRYV(8, 16, "pmx_nwsg16v_kernel<8,16>")
+            TRYV(8, 19, "pmx_nwsg16v_kernel<8,19>")
+            TRYV(8, 20, "pmx_nwsg16v_kernel<8,20>")
+        }
+        TRYV(16, 10, "pmx_nwsg16v_kernel<16,10>")
         TRYV(16, 16, "pmx_nwsg16v_kernel<16,16>")
         TRYV(32, 10, "pmx_nwsg16v_kernel<32,10>")
         TRYV(32, 16, "pmx_nwsg16v_kernel<32,16>")

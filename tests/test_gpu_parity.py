@@ -477,6 +477,19 @@ def test_nwsg16_first_generation_kernel(pkg, orc, monkeypatch):
     _nwsg_case(pkg, orc, 0, None, qs, rs, 5, 2, pm, om)
 
 
+@pytest.mark.parametrize("qmax", [100, 103, 127, 151, 159])
+def test_nwsg16_eight_lane_shapes(pkg, orc, qmax):
+    """the 8-lane shapes <8,13> <8,16> <8,19> <8,20> of the second-generation kernel (batches above 2048 pairs)"""
+    rng = np.random.default_rng(3270 + qmax)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 2100, max(1, qmax - 40), qmax)
+    qs[0] = random_seqs(rng, 1, qmax, qmax)[0]
+    rs = [mutate(rng, q, 0.1, 0.04) if rng.random() < 0.7 else random_seqs(rng, 1, 1, 220)[0] for q in qs]
+    for mode, sg in ((0, None), (1, None), (1, orc.S1_END | orc.S2_BEG)):
+        _nwsg_case(pkg, orc, mode, sg, qs, rs, 5, 2, pm, om)
+        assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_nwsg16v_kernel<8,")
+
+
 def test_nwsg16_long_references_and_skew_growth(pkg, orc):
     """second-generation kernel: the column skew grows with the reference length; long references, ext up to open"""
     rng = np.random.default_rng(3260)
