@@ -77,3 +77,9 @@ lens = np.exp(rng.uniform(np.log(500), np.log(5000), size=n)).astype(np.int64)
 roff = np.zeros(n + 1, dtype=np.int64); np.cumsum(lens, out=roff[1:])
 rbuf = DNA[rng.integers(0, 4, size=int(roff[-1]))]
 run("cfg5 sw_striped_sat 1kbp x 0.5-5kbp (length-sorted)", pkg.pmx_config_t(pkg.MODE_SW, 0, 5, 2, 0, 4, dna.inner), qbuf, qoff, rbuf, roff, 1000, 5000, reps=3)
+# short reads, global / semi-global score only (8-lane shapes of the second-generation kernel)
+n = 1000000
+qbuf = DNA[rng.integers(0, 4, size=n * 150)]; qoff = np.arange(n + 1, dtype=np.int64) * 150
+rbuf = DNA[rng.integers(0, 4, size=n * 150)]; roff = qoff.copy()
+run("sg_striped_16 150x150 (score only)", pkg.pmx_config_t(pkg.MODE_SG, 15, 5, 2, 16, 0, dna.inner), qbuf, qoff, rbuf, roff, 150, 150)
+run("nw_striped_16 150x150 (score only)", pkg.pmx_config_t(pkg.MODE_NW, 0, 5, 2, 16, 0, dna.inner), qbuf, qoff, rbuf, roff, 150, 150)
