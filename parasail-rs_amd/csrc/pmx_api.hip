@@ -1087,6 +1087,12 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         }
     }
     if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
+        // second generation (two pairs per lane slot); global / semi-global inside its exact window
+        const int rc = pmx_launch_stats16p(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, d_stats_out, st, &g_last_kernel);
+        if (rc < 0) { set_err("stats16p launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
+        if (rc == 0) return 0;
+    }
+    if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
         const int rc = pmx_launch_stats16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, d_stats_out, st, &g_last_kernel);
         if (rc < 0) { set_err("stats16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
         if (rc == 0) return 0;

@@ -725,7 +725,7 @@ static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
 
 // Second-generation eligibility: the profile byte score + open must fit, and the proven value range plus
 // the skew growth must fit the exact window with the bias chosen here.  Returns the bias, or 0.
-static int nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext)
+int pmx_nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext)
 {
     if (getenv("PMX_NWSG16_GEN1")) return 0;
     if (m.msize > PMX_MAX_FAST_MSIZE - 1 || open < ext || ext < 0 || b.max_rlen > 30000) return 0;
@@ -743,7 +743,7 @@ int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
                          int *variant, int *Tmax, size_t *trace_bytes)
 {
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
-    if (b.q_shared || b.perm || !nwsgv_bias(b, m, open, ext)) return 1;
+    if (b.q_shared || b.perm || !pmx_nwsgv_bias(b, m, open, ext)) return 1;
     int G = 0;
     for (int v = 0; v < 4 && !G; ++v) {                  // the first shape that holds the query and fits the LDS (launch_nwsgv's condition)
         const int g = 8 << v, np = 2 * (64 / g);
@@ -761,7 +761,7 @@ int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
 int pmx_launch_nwsgv_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                            pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream)
 {
-    const int nb = nwsgv_bias(b, m, open, ext);
+    const int nb = pmx_nwsgv_bias(b, m, open, ext);
     if (!nb) return 1;
     switch (variant) {
     case 0: return launch_nwsgv<8, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
@@ -783,7 +783,7 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
     if (b.max_rlen > 30000) return 1;
     const int q = b.max_qlen;
     // second-generation arithmetic (skewed columns, byte profile, VOP2) whenever its window holds
-    if (const int nb = nwsgv_bias(b, m, open, ext)) {
+    if (const int nb = pmx_nwsgv_bias(b, m, open, ext)) {
 #define TRYV(GG, RR, NAME)                                                      \
         if (q <= (GG) * (RR) - 1) {                                             \
             int rc = launch_nwsgv<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \

@@ -752,6 +752,25 @@ def test_stats16_sg_variants_and_sizes(pkg, orc, monkeypatch, by_trace):
         _stats_case(pkg, orc, 1, None, q2, r2, 5, 2, pm, om)
 
 
+@pytest.mark.parametrize("gaps", [(5, 2), (3, 3), (11, 1)])
+def test_stats16p_packed_kernel_everywhere(pkg, orc, monkeypatch, gaps):
+    """the packed statistics kernel forced for every global / semi-global case it can express (it is normally used
+    for the profile arm without free ends only): all free-end sets, ragged lengths, ties (open == ext)"""
+    monkeypatch.setenv("PMX_STATS16P_ALWAYS", "1")
+    monkeypatch.setenv("PMX_NO_STATS_BY_TRACE", "1")
+    rng = np.random.default_rng(5300 + gaps[0])
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 200, 1, 300)
+    rs = [mutate(rng, q, 0.12, 0.06) if i % 4 else random_seqs(rng, 1, 1, 400)[0] for i, q in enumerate(qs)]
+    _stats_case(pkg, orc, 0, None, qs, rs, gaps[0], gaps[1], pm, om)
+    assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_stats16p_kernel")
+    for sg in (orc.S1_BEG, orc.S2_END, orc.S1_END | orc.S2_BEG, orc.S1_BEG | orc.S2_BEG, orc.SG_ALL):
+        _stats_case(pkg, orc, 1, sg, qs[:80], rs[:80], gaps[0], gaps[1], pm, om)
+    q2 = random_seqs(rng, 12, 400, 640)
+    r2 = [mutate(rng, q, 0.1, 0.03) for q in q2]
+    _stats_case(pkg, orc, 0, None, q2, r2, gaps[0], gaps[1], pm, om)
+
+
 def test_stats16_shared_query_blosum62(pkg, orc):
     """config 3 shape through the 4-wave shared-profile variant"""
     rng = np.random.default_rng(5200)
