@@ -13,6 +13,8 @@
 //     diag, then F, then E; "open" only when strictly greater).  Every decision is the sign of a packed
 //     difference (v_pk_sub_i16, v_pk_ashrrev_i16 -> a 0xFFFF / 0 mask per half), every select one v_bfi_b32
 //     per statistic: 34 instructions per 2 cells against 2 x 24 in the unpacked kernel;
+//   * reference symbols are not staged in LDS (16 pairs of 5 kaa would take 80 KB and the occupancy with them):
+//     each lane fetches its next symbols from HBM two steps ahead (neighbouring lanes read neighbouring bytes);
 //   * match / similar increments come from two more byte planes of the LDS profile.  With a shared query
 //     (profile arm) the planes are built once per 4-wave workgroup.
 #include "pmx_common.h"
@@ -75,10 +77,9 @@ void pmx_stats16p_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__rest
     const int NPROF = q_shared ? 1 : NP;
     const int PLANE = NPROF * MS1 * QPS;        // bytes per plane
 
-    // LDS carve: [score plane][match plane][similar plane][rsym NP*RP][mat][map][ptab]
+    // LDS carve: [score plane][match plane][similar plane][mat][map][ptab]
     unsigned char *psc = lds, *pim = lds + PLANE, *pis = lds + 2 * PLANE;
-    unsigned char *rsym = lds + 3 * PLANE;
-    int16_t *mat = reinterpret_cast<int16_t *>(rsym + NP * RP);
+    int16_t *mat = reinterpret_cast<int16_t *>(lds + ((3 * PLANE + 7) & ~7));
     unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
     long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));
 
@@ -97,24 +98,6 @@ void pmx_stats16p_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__rest
     }
     __syncthreads();
 
-    // ---- reference symbols: G-1 virtual columns in front, pad behind -------------------------
-    constexpr int UB = NP < 8 ? NP : 8;
-    for (int p0 = 0; p0 < NP; p0 += UB) {
-        for (int j0 = 0; j0 < RP; j0 += NT) {
-            const int j = j0 + tid, jr = j - (G - 1);
-            unsigned char raw[UB]; bool ok[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int p = p0 + u;
-                ok[u] = jr >= 0 && jr < (int)ptab[5 * p + 3];
-                raw[u] = ok[u] ? rbuf[ptab[5 * p + 2] + jr] : (unsigned char)0;
-            }
-            if (j < RP) {
-#pragma unroll
-                for (int u = 0; u < UB; ++u) rsym[(p0 + u) * RP + j] = ok[u] ? map[raw[u]] : (unsigned char)msize;
-            }
-        }
-    }
     // ---- profile planes: query row i = l * R + k sits at byte l * RS + k (rows >= qlen score 0, no increments)
     const int vcol_b = col_pen ? 0 : open;      // real row x pad symbol (virtual column)
     for (int p = 0; p < NPROF; ++p) {
@@ -139,9 +122,16 @@ void pmx_stats16p_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__rest
     // ---- per-lane state ------------------------------------------------------------------
     const int prA = q_shared ? 0 : pA, prB = q_shared ? 0 : pB;
     const unsigned char *scA = psc + (size_t)prA * MS1 * QPS + g * RS, *scB = psc + (size_t)prB * MS1 * QPS + g * RS;
-    const unsigned char *rsA = rsym + pA * RP + (G - 1) - g, *rsB = rsym + pB * RP + (G - 1) - g;
     const int qlA = (int)ptab[5 * pA + 1], qlB = (int)ptab[5 * pB + 1];
     const int rlA = (int)ptab[5 * pA + 3], rlB = (int)ptab[5 * pB + 3];
+    const uint8_t *refA = rbuf + ptab[5 * pA + 2], *refB = rbuf + ptab[5 * pB + 2];
+    // symbol of step x for this lane: column x - g of the reference, the pad symbol outside it
+    auto fetch = [&](int x, int &ra, int &rb) {
+        const int col = x - g;
+        ra = (col >= 0 && col < rlA) ? (int)refA[col] : -1;
+        rb = (col >= 0 && col < rlB) ? (int)refB[col] : -1;
+    };
+    auto sym_of = [&](int raw) -> int { return raw < 0 ? msize : (int)map[raw]; };
     auto pack2 = [](int a, int b) -> int { return (a & 0xFFFF) | (b << 16); };
     const int vExt = pack2(ext, ext), vC = pack2(open - ext, open - ext);
     const int one2 = 0x00010001;
@@ -278,16 +268,22 @@ void pmx_stats16p_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__rest
 #pragma unroll
     for (int p = 0; p < NPW; ++p) max_rlen = max(max_rlen, (int)ptab[5 * (wave * NPW + p) + 3]);
     const int T_ = (max_rlen + G - 1 + 1) & ~1;
-    load_planes(0, rsA[0], rsB[0]);
-    int nsA = rsA[1], nsB = rsB[1];
+    // pipeline: raw bytes two steps ahead (HBM / L2 latency), mapped symbols one step ahead, profile words for the next step
+    int r0a, r0b, r1a, r1b, r2a, r2b, r3a, r3b;
+    fetch(0, r0a, r0b); fetch(1, r1a, r1b); fetch(2, r2a, r2b); fetch(3, r3a, r3b);
+    load_planes(0, sym_of(r0a), sym_of(r0b));
+    int nsA = sym_of(r1a), nsB = sym_of(r1b);          // symbols of step t + 1
+    int m2a = r2a, m2b = r2b, m3a = r3a, m3b = r3b;    // raw bytes of steps t + 2, t + 3
     for (int t = 0; t < T_; t += 2) {
         load_planes(1, nsA, nsB);
-        nsA = rsA[t + 2]; nsB = rsB[t + 2];
+        nsA = sym_of(m2a); nsB = sym_of(m2b);           // step t + 2
+        fetch(t + 4, m2a, m2b);
         __builtin_amdgcn_sched_barrier(0);
         step(0, t);
         __builtin_amdgcn_sched_barrier(0);
         load_planes(0, nsA, nsB);
-        nsA = rsA[t + 3]; nsB = rsB[t + 3];
+        nsA = sym_of(m3a); nsB = sym_of(m3b);           // step t + 3
+        fetch(t + 5, m3a, m3b);
         __builtin_amdgcn_sched_barrier(0);
         step(1, t + 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -339,7 +335,7 @@ static int launch_statsp(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
     constexpr int RS = (R + 3) / 4 * 4, NP = 2 * (64 / G) * WAVES;
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
     const int nprof = b.q_shared ? 1 : NP;
-    const size_t lds = (size_t)3 * nprof * (m.msize + 1) * G * RS + (size_t)NP * RP +
+    const size_t lds = (size_t)3 * nprof * (m.msize + 1) * G * RS + 8 +
                        (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
     if (lds > 160 * 1024) return 1;
     { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_stats16p_kernel<G, R, WAVES>)); if (rc) return rc; }
