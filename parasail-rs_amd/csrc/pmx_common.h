@@ -56,6 +56,11 @@ int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
 int pmx_launch_nwsgv_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                            pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream);
 
+// Shared-query variant of the local kernel (pmx_sw16q.hip); called by pmx_launch_sw16 once the skewed byte-profile
+// variant's conditions hold.  0 launched, 1 not eligible, <0 HIP error.
+int pmx_launch_sw16q(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
+                     pmx_record_t *d_out, hipStream_t stream, const char **kernel_name);
+
 // Length-sorted processing order for ragged batches (pmx_sort.hip).
 size_t pmx_sort_scratch_bytes(long long n);
 int pmx_build_length_perm(const int64_t *d_roff, long long n, void *scratch, const unsigned **perm_out, hipStream_t stream);

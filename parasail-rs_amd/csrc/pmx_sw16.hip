@@ -618,6 +618,11 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                     feasible + M3_BIAS < (long long)M3_LIMIT(m.max) - (long long)(b.max_rlen + 2 * 64 + 4) * ext;
     // alphabets of <= 4 letters (+ wildcard): no LDS profile, the v_perm looks the score up (see PT in the kernel)
     const bool pt = sk && u8ok && m.msize <= 5 && b.retry_list && b.retry_count && !b.q_has_wildcard && !getenv("PMX_SW16_NO_PERMTABLE");
+    // one shared query (profile arm) with a real LDS profile: the workgroup-shared-profile kernel (pmx_sw16q.hip)
+    if (b.q_shared && var == 2 && u8ok && sk && !pt) {
+        const int rc = pmx_launch_sw16q(b, m, open, ext, d_out, stream, kernel_name);
+        if (rc <= 0) return rc;
+    }
 #define TRY(GG, RR, NAME)                                                       \
     if (q <= (GG) * (RR)) {                                                     \
         constexpr int R4 = (RR) % 4 == 0 ? (RR) : 4;                            \

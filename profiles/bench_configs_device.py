@@ -83,3 +83,20 @@ qbuf = DNA[rng.integers(0, 4, size=n * 150)]; qoff = np.arange(n + 1, dtype=np.i
 rbuf = DNA[rng.integers(0, 4, size=n * 150)]; roff = qoff.copy()
 run("sg_striped_16 150x150 (score only)", pkg.pmx_config_t(pkg.MODE_SG, 15, 5, 2, 16, 0, dna.inner), qbuf, qoff, rbuf, roff, 150, 150)
 run("nw_striped_16 150x150 (score only)", pkg.pmx_config_t(pkg.MODE_NW, 0, 5, 2, 16, 0, dna.inner), qbuf, qoff, rbuf, roff, 150, 150)
+# classic protein database search: one 300-aa query (reused profile) against 20k references of 4.5-5 kaa, local, BLOSUM62 11/1
+n = 20000
+q = AA[rng.integers(0, 20, size=300)]
+rbuf, roff = randbatch(n, 4500, 5000, AA)
+prof = pkg.Profile.new(q.tobytes(), False, b62)
+cfgp = pkg.pmx_config_t(pkg.MODE_SW, 0, 11, 1, 16, 0, b62.inner)
+d_r = torch.from_numpy(rbuf).to(dev); d_ro = torch.from_numpy(roff).to(dev)
+outp = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+def oncesw():
+    pkg.align_profile_batch_device(cfgp, prof, n, d_r.data_ptr(), d_ro.data_ptr(), 5000, outp.data_ptr(), None, stream.cuda_stream)
+oncesw(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(stream)
+for _ in range(3): oncesw()
+e1.record(stream); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 3
+print("%-44s n=%-7d %8.1f GCUPS  (%.3f ms, %s)" % ("sw_striped_profile_16 300aa x ~4.75kaa BLOSUM62", n, 300 * int((roff[1:] - roff[:-1]).sum()) / ms / 1e6, ms, pkg.lib.pmx_last_kernel().decode()))

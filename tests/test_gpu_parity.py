@@ -361,6 +361,31 @@ def test_sw16_width8_batches(pkg, orc):
         assert one.is_saturated() == bool(w.saturated)
 
 
+@pytest.mark.parametrize("qlen", [100, 250, 320, 500, 1000, 2000])
+def test_sw16q_shared_query_protein_database_search(pkg, orc, qlen):
+    """the profile arm of local alignment (one protein query, BLOSUM62 11/1, many references): the workgroup-shared
+    profile kernel in each of its shapes, ragged reference lengths (length-sorted order), planted homologs"""
+    rng = np.random.default_rng(1600 + qlen)
+    pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    q = random_seqs(rng, 1, qlen, qlen, AA)[0]
+    n = 400 if qlen <= 500 else 120
+    rs = random_seqs(rng, n, 30, 900, AA)
+    for k in range(0, n, 5):
+        pos = int(rng.integers(0, max(1, len(rs[k]) - 10)))
+        rs[k] = (rs[k][:pos] + mutate(rng, q, 0.3, 0.04, AA)[: 600] + rs[k][pos:])[:1200]
+    rs[1] = rs[1].lower()
+    qb, qo = orc.pack([q] * n); rb, ro = orc.pack(rs)
+    want = orc.align_batch(orc.SW, qb, qo, rb, ro, 11, 1, om)
+    for width in (16, 0):
+        b = pkg.Aligner.new().local().profile(pkg.Profile.new(q, False, pm)).matrix(pm).gap_open(11).gap_extend(1)
+        if width:
+            b.solution_width(width)
+        got = b.build().align_batch([], rs)
+        assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_sw16q_kernel")
+        assert (got["score"] == want[:, 0]).all() and (got["end_query"] == want[:, 1]).all() \
+            and (got["end_ref"] == want[:, 2]).all() and (got["flags"] == 0).all()
+
+
 def test_sw16_saturating_int16_variant(pkg, orc):
     """scores too large for the max3 lanes (matrix max > 2048) take the saturating-int16 variant"""
     rng = np.random.default_rng(1450)
