@@ -678,6 +678,248 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Shared query (profile arm: `nw_*_profile_*`, `sg*_profile_*`, /root/reference/src/aligner/mod.rs:431-450): the
+// second-generation arithmetic with ONE profile per 4-wave workgroup (virtual rows included: they are the same for
+// every pair) and reference symbols fetched from HBM two steps ahead instead of being staged in LDS -- what
+// pmx_sw16q.hip does for local alignment.  A protein profile plus four staged 5-kaa references cost 58 KB per
+// wave otherwise.
+template <int G, int R, int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
+void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
+                        const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
+                        long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
+                        int msize, int open, int ext,
+                        int col_pen, int row_pen, int s1_end, int s2_end, int nb,
+                        const unsigned *__restrict__ perm,
+                        pmx_record_t *__restrict__ out)
+{
+    constexpr int RS = (R + 3) / 4 * 4;
+    constexpr int QP = G * R;
+    constexpr int QPS = G * RS;
+    constexpr int NPW = 2 * (64 / G);
+    constexpr int NP = NPW * WAVES;
+    constexpr int NT = 64 * WAVES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane % G, slotw = lane / G;
+    const int pA = wave * NPW + 2 * slotw, pB = pA + 1;
+    const int MS1 = msize + 1;
+
+    unsigned char *psc = lds;                   // [MS1][QPS]
+    int16_t *mat = reinterpret_cast<int16_t *>(lds + ((MS1 * QPS + 7) & ~7));
+    unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
+    long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));   // per pair: r offset, rlen, pair index
+
+    const long long pair0 = (long long)blockIdx.x * NP;
+    for (int i = tid; i < msize * msize; i += NT) mat[i] = gmat[i];
+    for (int i = tid; i < 256; i += NT) map[i] = gmap[i];
+    if (tid < NP) {
+        long long pos = pair0 + tid; if (pos >= n) pos = n - 1;
+        const long long pi = perm ? (long long)perm[pos] : pos;
+        const long long rb = roff[pi];
+        ptab[3 * tid + 0] = rb;
+        ptab[3 * tid + 1] = roff[pi + 1] - rb;
+        ptab[3 * tid + 2] = (pair0 + tid < n) ? pi : -1;
+    }
+    __syncthreads();
+    // the shared byte profile: logical row er = l * R + k at byte l * RS + k; P virtual rows on top
+    const int P = QP - qlen;
+    const int vrow_b = row_pen ? 0 : open, vcol_b = col_pen ? 0 : open;
+    for (int er = tid; er < QP; er += NT) {
+        unsigned char *sc = psc + (er / R) * RS + er % R;
+        if (er >= P) {
+            const int q = map[qbuf[er - P]];
+            for (int sym = 0; sym < msize; ++sym) sc[sym * QPS] = (unsigned char)(mat[q * msize + sym] + open);
+            sc[msize * QPS] = (unsigned char)vcol_b;
+        } else {
+            for (int sym = 0; sym < msize; ++sym) sc[sym * QPS] = (unsigned char)vrow_b;
+            sc[msize * QPS] = (unsigned char)open;          // virtual x virtual: score 0
+        }
+    }
+    __syncthreads();
+
+    const unsigned char *scL = psc + g * RS;
+    const int rlA = (int)ptab[3 * pA + 1], rlB = (int)ptab[3 * pB + 1];
+    const uint8_t *refA = rbuf + ptab[3 * pA + 0], *refB = rbuf + ptab[3 * pB + 0];
+    auto fetch = [&](int x, int &ra, int &rb) {
+        const int col = x - g;
+        ra = (col >= 0 && col < rlA) ? (int)refA[col] : -1;
+        rb = (col >= 0 && col < rlB) ? (int)refB[col] : -1;
+    };
+    auto sym_of = [&](int raw) -> int { return raw < 0 ? msize : (int)map[raw]; };
+
+    auto pack2 = [](int a, int b) -> int { return (a & 0xFFFF) | (b << 16); };
+    const int vExt = pack2(ext, ext), vC = pack2(open - ext, open - ext);
+    const v2us one2 = {1, 1};
+    const int base = nb + (G - g) * ext - open;
+    auto left_h = [&](int erow) -> int { const int i = erow - P; return (i >= 0 && col_pen) ? -(open + i * ext) : 0; };
+    auto below_f = [&](int erow) -> int { const int i = erow - P; return (i >= 0 && col_pen) ? -(open + i * ext) : -open; };
+
+    int X[R], E[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { const int v = base + left_h(g * R + k); X[k] = pack2(v, v); E[k] = X[k]; }
+    int Hout = X[R - 1];
+    int Fout; { const int v = base + open + below_f((g + 1) * R); Fout = pack2(v, v); }
+    int diag0; { const int v = (g == 0) ? base : base + left_h(g * R - 1); diag0 = pack2(v, v); }
+    int topX = row_pen ? pack2(nb + (G + 1) * ext - 2 * open, nb + (G + 1) * ext - 2 * open)
+                       : pack2(nb + (G + 1) * ext - open, nb + (G + 1) * ext - open);
+    const int topStep = row_pen ? 0 : vExt;
+    int skewX = pack2((G - g + 1) * ext - open, (G - g + 1) * ext - open);
+
+    const v2s rl1 = PK(pack2(rlA - 1, rlB - 1)), rlv = PK(pack2(rlA, rlB));
+    int jj = ((-g) & 0xFFFF) * 0x00010001;
+    int res = 0;
+    v2s bestrow = PK(0); int bestrowj = 0;
+    v2s bestcol = PK(0); int bestcoli = 0;
+
+    int w[2][2][RS / 4];
+    auto load_scores = [&](int bsel, int symA, int symB) {
+        const int *a = reinterpret_cast<const int *>(scL + symA * QPS), *b = reinterpret_cast<const int *>(scL + symB * QPS);
+#pragma unroll
+        for (int x = 0; x < RS / 4; ++x) { w[bsel][0][x] = a[x]; w[bsel][1][x] = b[x]; }
+    };
+    auto step = [&](int bsel) {
+        const int Hin = n_shift_up<G>(Hout, topX, g);
+        int F = n_shift_up<G>(Fout, topX, g);
+        int Tpre[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int s = __builtin_amdgcn_perm(w[bsel][1][k / 4], w[bsel][0][k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16));
+            Tpre[k] = ((k == 0) ? diag0 : X[k - 1]) + s;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int Fe = F - vExt;
+            const int H = I32(n_max3f(PK(Tpre[k]), PK(E[k]), PK(Fe)));
+            const int Xn = H - vC;
+            E[k] = I32(n_max3f(PK(E[k]), PK(Xn), PK(Xn)));
+            F = I32(n_max3f(PK(Fe), PK(Xn), PK(Xn)));
+            X[k] = Xn;
+        }
+        diag0 = Hin;
+        Hout = X[R - 1];
+        Fout = F;
+        // ---- captures (as in pmx_nwsg16v_kernel) ----
+        const v2s jv = PK(jj);
+        const int mLast = m_eq(jv, rl1);
+        res = n_bfi(mLast, Hout, res);
+        if (s2_end) {
+            const v2s cand = PK(I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, Hout) - __builtin_bit_cast(v2us, skewX))));
+            const int imp = m_lt(bestrow, cand) & m_ult(jv, rlv);
+            bestrow = PK(n_bfi(imp, I32(cand), I32(bestrow)));
+            bestrowj = n_bfi(imp, jj, bestrowj);
+        }
+        if (s1_end && __builtin_amdgcn_ballot_w64(mLast != 0) != 0) {
+            v2s cm = PK(0); int krow = 0;
+            v2s vals[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int er = g * R + k;
+                vals[k] = PK(er >= P ? X[k] : 0);
+                cm = n_max3f(cm, vals[k], vals[k]);
+            }
+#pragma unroll
+            for (int k = R - 1; k >= 0; --k) {
+                const int er = g * R + k;
+                krow = n_bfi(m_eq(vals[k], cm), pack2(er, er), krow);
+            }
+            const int imp = m_lt(bestcol, cm) & mLast;
+            bestcol = PK(n_bfi(imp, I32(cm), I32(bestcol)));
+            bestcoli = n_bfi(imp, krow, bestcoli);
+        }
+        jj = I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, jj) + one2));
+        skewX = I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, skewX) + __builtin_bit_cast(v2us, vExt)));
+        topX += topStep;
+    };
+
+    int max_rlen = 0;
+#pragma unroll
+    for (int p = 0; p < NPW; ++p) max_rlen = max(max_rlen, (int)ptab[3 * (wave * NPW + p) + 1]);
+    const int T = (max_rlen + G - 1 + 1) & ~1;
+    int r0a, r0b, r1a, r1b, m2a, m2b, m3a, m3b;
+    fetch(0, r0a, r0b); fetch(1, r1a, r1b); fetch(2, m2a, m2b); fetch(3, m3a, m3b);
+    load_scores(0, sym_of(r0a), sym_of(r0b));
+    int nsA = sym_of(r1a), nsB = sym_of(r1b);
+    for (int t = 0; t < T; t += 2) {
+        load_scores(1, nsA, nsB);
+        nsA = sym_of(m2a); nsB = sym_of(m2b);
+        fetch(t + 4, m2a, m2b);
+        __builtin_amdgcn_sched_barrier(0);
+        step(0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_scores(0, nsA, nsB);
+        nsA = sym_of(m3a); nsB = sym_of(m3b);
+        fetch(t + 5, m3a, m3b);
+        __builtin_amdgcn_sched_barrier(0);
+        step(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    unsigned keyA = ((unsigned)(I32(bestcol) & 0xFFFF) << 16) | (0xFFFFu - (unsigned)(bestcoli & 0xFFFF));
+    unsigned keyB = ((unsigned)((unsigned)I32(bestcol) >> 16) << 16) | (0xFFFFu - ((unsigned)bestcoli >> 16));
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) {
+        const unsigned oa = __shfl_xor(keyA, off, 64), ob = __shfl_xor(keyB, off, 64);
+        keyA = oa > keyA ? oa : keyA;
+        keyB = ob > keyB ? ob : keyB;
+    }
+    const int lastlane = slotw * G + G - 1;
+    const int resL = __shfl(res, lastlane, 64);
+    const int browL = __shfl(I32(bestrow), lastlane, 64), browjL = __shfl(bestrowj, lastlane, 64);
+    if (g == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long pi = ptab[3 * (h ? pB : pA) + 2];
+            if (pi >= 0) {
+                const int ql = qlen, rl = h ? rlB : rlA;
+                const int unsk = nb + (rl - 1 + G) * ext - open + ext;
+                const int corner = (int)(h ? ((unsigned)resL >> 16) : (resL & 0xFFFF)) - unsk;
+                pmx_record_t rec;
+                rec.flags = 0;
+                if (!s1_end && !s2_end) { rec.score = corner; rec.end_query = ql - 1; rec.end_ref = rl - 1; }
+                else {
+                    int best = -2147483647 - 1, ei = 0, ej = 0;
+                    if (s2_end) {
+                        best = (int)(h ? ((unsigned)browL >> 16) : (browL & 0xFFFF)) - nb;
+                        ei = ql - 1; ej = (int)(h ? ((unsigned)browjL >> 16) : (browjL & 0xFFFF));
+                    }
+                    if (s1_end) {
+                        const unsigned key = h ? keyB : keyA;
+                        const int cv = (int)(key >> 16) - unsk;
+                        if (cv > best) { best = cv; ei = (int)(0xFFFFu - (key & 0xFFFFu)) - P; ej = rl - 1; }
+                    }
+                    rec.score = best; rec.end_query = ei; rec.end_ref = ej;
+                }
+                out[pi] = rec;
+            }
+        }
+    }
+}
+
+template <int G, int R>
+static int launch_nwsgq(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
+                        pmx_record_t *d_out, hipStream_t stream)
+{
+    constexpr int RS = (R + 3) / 4 * 4, WAVES = 4, NP = 2 * (64 / G) * WAVES;
+    const size_t lds = (size_t)(m.msize + 1) * G * RS + 8 + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 24;
+    if (lds > 160 * 1024) return 1;
+    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16q_kernel<G, R, WAVES>)); if (rc) return rc; }
+    const bool sg = mode == PMX_MODE_SG;
+    const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
+    const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
+    const long long blocks = (b.n + NP - 1) / NP;
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL((pmx_nwsg16q_kernel<G, R, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream,
+                       b.qbuf, b.q_shared, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper, m.msize, open, ext,
+                       col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
 // ------------------------------------------------------------------------ host side ----
 template <int G, int R>
 static int launch_nwsg(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
@@ -784,6 +1026,20 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
     const int q = b.max_qlen;
     // second-generation arithmetic (skewed columns, byte profile, VOP2) whenever its window holds
     if (const int nb = pmx_nwsgv_bias(b, m, open, ext)) {
+        if (b.q_shared && !getenv("PMX_NWSG16_NO_SHARED")) {        // profile arm: one profile per workgroup, references from HBM
+#define TRYQ(GG, RR, NAME)                                                      \
+            if (q <= (GG) * (RR) - 1) {                                         \
+                int rc = launch_nwsgq<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
+                if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; } \
+            }
+            TRYQ(16, 10, "pmx_nwsg16q_kernel<16,10>/shared profile")
+            TRYQ(16, 16, "pmx_nwsg16q_kernel<16,16>/shared profile")
+            TRYQ(32, 10, "pmx_nwsg16q_kernel<32,10>/shared profile")
+            TRYQ(32, 16, "pmx_nwsg16q_kernel<32,16>/shared profile")
+            TRYQ(64, 16, "pmx_nwsg16q_kernel<64,16>/shared profile")
+            TRYQ(64, 32, "pmx_nwsg16q_kernel<64,32>/shared profile")
+#undef TRYQ
+        }
 #define TRYV(GG, RR, NAME)                                                      \
         if (q <= (GG) * (RR) - 1) {                                             \
             int rc = launch_nwsgv<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \

@@ -100,3 +100,13 @@ for _ in range(3): oncesw()
 e1.record(stream); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
 print("%-44s n=%-7d %8.1f GCUPS  (%.3f ms, %s)" % ("sw_striped_profile_16 300aa x ~4.75kaa BLOSUM62", n, 300 * int((roff[1:] - roff[:-1]).sum()) / ms / 1e6, ms, pkg.lib.pmx_last_kernel().decode()))
+cfgn = pkg.pmx_config_t(pkg.MODE_NW, 0, 11, 1, 16, 0, b62.inner)
+def oncenw():
+    pkg.align_profile_batch_device(cfgn, prof, n, d_r.data_ptr(), d_ro.data_ptr(), 5000, outp.data_ptr(), None, stream.cuda_stream)
+oncenw(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(stream)
+for _ in range(3): oncenw()
+e1.record(stream); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 3
+print("%-44s n=%-7d %8.1f GCUPS  (%.3f ms, %s)" % ("nw_striped_profile_16 300aa x ~4.75kaa BLOSUM62", n, 300 * int((roff[1:] - roff[:-1]).sum()) / ms / 1e6, ms, pkg.lib.pmx_last_kernel().decode()))

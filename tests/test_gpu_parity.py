@@ -526,6 +526,29 @@ def test_nwsg16_long_references_and_skew_growth(pkg, orc):
         _nwsg_case(pkg, orc, mode, sg, qs, rs, 3, 3, pm, om, expect_kernel=None)
 
 
+@pytest.mark.parametrize("qlen", [90, 159, 300, 511, 1000, 2000])
+def test_nwsg16q_shared_query_profile_arm(pkg, orc, qlen):
+    """global / semi-global with one reused protein profile: the workgroup-shared-profile kernel in each shape"""
+    rng = np.random.default_rng(3400 + qlen)
+    pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    q = random_seqs(rng, 1, qlen, qlen, AA)[0]
+    n = 300 if qlen <= 511 else 60
+    rs = [mutate(rng, q, 0.3, 0.05, AA) if rng.random() < 0.5 else random_seqs(rng, 1, 20, qlen + 300, AA)[0] for _ in range(n)]
+    qb, qo = orc.pack([q] * n); rb, ro = orc.pack(rs)
+    for mode, sg in ((0, None), (1, None), (1, orc.S1_BEG | orc.S2_END), (1, orc.S2_BEG | orc.S2_END), (1, orc.S1_END)):
+        b = pkg.Aligner.new().profile(pkg.Profile.new(q, False, pm)).matrix(pm).gap_open(11).gap_extend(1).solution_width(16)
+        [b.global_, b.semi_global][mode]()
+        if mode == 1 and sg is not None:
+            qg = [t for f, t in ((orc.S1_BEG, "prefix"), (orc.S1_END, "suffix")) if sg & f]
+            dg = [t for f, t in ((orc.S2_BEG, "prefix"), (orc.S2_END, "suffix")) if sg & f]
+            b.allow_query_gaps(qg).allow_ref_gaps(dg)
+        got = b.build().align_batch([], rs)
+        assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_nwsg16q_kernel")
+        want = orc.align_batch(mode, qb, qo, rb, ro, 11, 1, om, sg_flags=sg if sg is not None else orc.SG_ALL, bits=16)
+        bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
+        assert len(bad) == 0, (mode, sg, bad[:5], got[bad[:5]], want[bad[:5]])
+
+
 def test_nwsg16_falls_back_outside_the_exact_window(pkg, orc):
     """long sequences with large penalties leave the biased 16-bit window: the general kernel takes over"""
     rng = np.random.default_rng(3300)
