@@ -382,7 +382,9 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
 //     decision is the sign of one packed difference, pushed into a packed plane (16 bits = 4 rows per
 //     half): 3 instructions per decision and 2 cells.  Per lane and step one 16-byte store, coalesced over the
 //     wave: [pair A rows 0-7, A rows 8-15, B rows 0-7, B rows 8-15], row 0 in the top nibble.  
-template <int G, int R, bool TR>
+//   * FETCH (long references): reference symbols are not staged in LDS, each lane fetches its next symbols from HBM
+//     two steps ahead (see pmx_sw16q.hip); the staged copies of four 5-kaa references would halve the occupancy.
+template <int G, int R, bool TR, bool FETCH = false>
 __global__ __launch_bounds__(64)
 void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                         const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
@@ -408,7 +410,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     const int PROF_STRIDE = MS1 * QPS;
 
     unsigned char *rsym = lds + NP * PROF_STRIDE;
-    int16_t *mat = reinterpret_cast<int16_t *>(rsym + NP * RP);
+    int16_t *mat = reinterpret_cast<int16_t *>(rsym + (FETCH ? 0 : NP * RP));
     unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
     long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));
 
@@ -432,7 +434,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 #pragma unroll
     for (int p = 0; p < NP; ++p) max_rlen = max(max_rlen, (int)ptab[5 * p + 3]);
     constexpr int UB = NP < 8 ? NP : 8;
-    for (int p0 = 0; p0 < NP; p0 += UB) {
+    for (int p0 = 0; p0 < (FETCH ? 0 : NP); p0 += UB) {
         for (int j0 = 0; j0 < RP; j0 += 64) {
             const int j = j0 + lane, jr = j - (G - 1);
             unsigned char raw[UB]; bool ok[UB];
@@ -619,16 +621,33 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 
     const int T = (max_rlen + G - 1 + 1) & ~1;
     int w0a[RS / 4], w0b[RS / 4], w1a[RS / 4], w1b[RS / 4];
-    load_scores(rsA[0], rsB[0], w0a, w0b);
-    int nsA = rsA[1], nsB = rsB[1];
+    const uint8_t *refA = rbuf + ptab[5 * pA + 2], *refB = rbuf + ptab[5 * pB + 2];
+    auto fetch = [&](int x, int &ra, int &rb) {      // FETCH: raw byte of step x (column x - g), -1 outside the reference
+        const int col = x - g;
+        ra = (col >= 0 && col < rlA) ? (int)refA[col] : -1;
+        rb = (col >= 0 && col < rlB) ? (int)refB[col] : -1;
+    };
+    auto sym_of = [&](int raw) -> int { return raw < 0 ? msize : (int)map[raw]; };
+    int m2a = 0, m2b = 0, m3a = 0, m3b = 0, nsA, nsB;
+    if (FETCH) {
+        int r0a, r0b, r1a, r1b;
+        fetch(0, r0a, r0b); fetch(1, r1a, r1b); fetch(2, m2a, m2b); fetch(3, m3a, m3b);
+        load_scores(sym_of(r0a), sym_of(r0b), w0a, w0b);
+        nsA = sym_of(r1a); nsB = sym_of(r1b);
+    } else {
+        load_scores(rsA[0], rsB[0], w0a, w0b);
+        nsA = rsA[1]; nsB = rsB[1];
+    }
     for (int t = 0; t < T; t += 2) {
         load_scores(nsA, nsB, w1a, w1b);
-        nsA = rsA[t + 2]; nsB = rsB[t + 2];
+        if (FETCH) { nsA = sym_of(m2a); nsB = sym_of(m2b); fetch(t + 4, m2a, m2b); }
+        else { nsA = rsA[t + 2]; nsB = rsB[t + 2]; }
         __builtin_amdgcn_sched_barrier(0);
         step(HA, HB, w0a, w0b, t);
         __builtin_amdgcn_sched_barrier(0);
         load_scores(nsA, nsB, w0a, w0b);
-        nsA = rsA[t + 3]; nsB = rsB[t + 3];
+        if (FETCH) { nsA = sym_of(m3a); nsB = sym_of(m3b); fetch(t + 5, m3a, m3b); }
+        else { nsA = rsA[t + 3]; nsB = rsB[t + 3]; }
         __builtin_amdgcn_sched_barrier(0);
         step(HB, HA, w1a, w1b, t + 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -943,22 +962,22 @@ static int launch_nwsg(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
     return e == hipSuccess ? 0 : -(int)e;
 }
 
-template <int G, int R, bool TR = false>
+template <int G, int R, bool TR = false, bool FETCH = false>
 static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
                         pmx_record_t *d_out, hipStream_t stream, uint32_t *tbuf = nullptr, int Tmax = 0)
 {
     constexpr int RS = (R + 3) / 4 * 4, NP = 2 * (64 / G);
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
-    const size_t lds = (size_t)NP * (m.msize + 1) * G * RS + (size_t)NP * RP +
+    const size_t lds = (size_t)NP * (m.msize + 1) * G * RS + (FETCH ? 0 : (size_t)NP * RP) +
                        (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
     if (lds > 160 * 1024) return 1;
-    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R, TR>)); if (rc) return rc; }
+    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R, TR, FETCH>)); if (rc) return rc; }
     const bool sg = mode == PMX_MODE_SG;
     const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR>), dim3((unsigned)blocks), dim3(64), lds, stream,
+    hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, FETCH>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                        m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax);
     hipError_t e = hipGetLastError();
@@ -1040,10 +1059,12 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
             TRYQ(64, 32, "pmx_nwsg16q_kernel<64,32>/shared profile")
 #undef TRYQ
         }
+        const bool longref = b.max_rlen >= 1024 && !getenv("PMX_NWSG16_NO_FETCH");   // staged references would dominate the LDS
 #define TRYV(GG, RR, NAME)                                                      \
         if (q <= (GG) * (RR) - 1) {                                             \
-            int rc = launch_nwsgv<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
-            if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; }   \
+            int rc = longref ? launch_nwsgv<GG, RR, false, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream) \
+                             : launch_nwsgv<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
+            if (rc <= 0) { if (kernel_name) *kernel_name = longref ? NAME "/fetch" : NAME; return rc; }   \
         }
         if (b.n > 2048) {       // (few pairs: latency counts, the 16-lane shapes have half the work per step)
             TRYV(8, 13, "pmx_nwsg16v_kernel<8,13>")      // reads of 100 / 125 / 150 bp: few padding rows
