@@ -114,7 +114,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
                                        //   expressed: such pairs are flagged PMX_FLAG_RETRY16 and redone with the LDS profile.
     constexpr bool TR = VAR == 7;      // VAR 5 + packed 4-bit traceback output (see pmx_nwsg16.hip: same bits, same layout; rows top-aligned here)
     static_assert(!TR || R == 16, "trace: four packed planes of 4 rows");
-    constexpr bool U8 = VAR == 3 || VAR == 5 || PT || TR;   // + one-byte profile entries (score + open fits 0..255): half the LDS, same v_perm count
+    constexpr bool FETCH = VAR == 8;   // VAR 5 + reference symbols fetched from HBM two steps ahead instead of staged in LDS (long references)
+    constexpr bool U8 = VAR == 3 || VAR == 5 || PT || TR || FETCH;   // + one-byte profile entries (score + open fits 0..255): half the LDS, same v_perm count
     constexpr bool SK = VAR >= 4;      // + column-skewed values (everything in column j carries +(j+G)*ext): E needs no subtract
     constexpr int EB = U8 ? 1 : 2;     // bytes per profile entry
     constexpr int WR = U8 ? 4 : 2;     // rows per loaded dword
@@ -136,7 +137,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     // value (NP - p) * msize, so no per-pair copy is needed.
     int16_t *prof = reinterpret_cast<int16_t *>(lds);
     unsigned char *rsym = lds + (PT ? 0 : NP * PROF_STRIDE + QP * EB);
-    int16_t *mat = reinterpret_cast<int16_t *>(rsym + NP * RP);
+    int16_t *mat = reinterpret_cast<int16_t *>(rsym + (FETCH ? 0 : NP * RP));
     unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
     long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));   // per pair: q offset, qlen, r offset, rlen, pair index
 
@@ -171,7 +172,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     // flight before anything consumes them (the prologue is latency-bound otherwise), and no
     // index needs a division.
     constexpr int UB = NP < 8 ? NP : 8;
-    for (int p0 = 0; p0 < NP; p0 += UB) {
+    for (int p0 = 0; p0 < (FETCH ? 0 : NP); p0 += UB) {
         for (int j0 = 0; j0 < RP; j0 += 64) {
             const int j = j0 + lane, jr = j - (G - 1);
             unsigned char raw[UB]; bool ok[UB];
@@ -452,16 +453,36 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     // software pipeline: scores of step t+1 are fetched from LDS while step t computes
     const int T = max_rlen + G - 1;                      // steps: the last lane's last real column
     int w0a[RS / WR], w0b[RS / WR], w1a[RS / WR], w1b[RS / WR];
-    load_scores(rsA[0], rsB[0], w0a, w0b);
-    int nsA = rsA[1], nsB = rsB[1];
+    // FETCH: raw byte of step x (column x - g), -1 outside the reference; the pad symbol is the pair's own
+    const int rlA_ = (int)ptab[5 * pA + 3], rlB_ = (int)ptab[5 * pB + 3];
+    const uint8_t *refA = rbase + ptab[5 * pA + 2], *refB = rbase + ptab[5 * pB + 2];
+    auto fetch = [&](int x, int &ra, int &rb) {
+        const int col = x - g;
+        ra = (col >= 0 && col < rlA_) ? (int)refA[col] : -1;
+        rb = (col >= 0 && col < rlB_) ? (int)refB[col] : -1;
+    };
+    auto symA_of = [&](int raw) -> int { return raw < 0 ? (NP - pA) * msize : (int)map[raw]; };
+    auto symB_of = [&](int raw) -> int { return raw < 0 ? (NP - pB) * msize : (int)map[raw]; };
+    int m2a = 0, m2b = 0, m3a = 0, m3b = 0, nsA, nsB;
+    if (FETCH) {
+        int r0a, r0b, r1a, r1b;
+        fetch(0, r0a, r0b); fetch(1, r1a, r1b); fetch(2, m2a, m2b); fetch(3, m3a, m3b);
+        load_scores(symA_of(r0a), symB_of(r0b), w0a, w0b);
+        nsA = symA_of(r1a); nsB = symB_of(r1b);
+    } else {
+        load_scores(rsA[0], rsB[0], w0a, w0b);
+        nsA = rsA[1]; nsB = rsB[1];
+    }
     for (int t = 0; t + 1 < T; t += 2) {
         load_scores(nsA, nsB, w1a, w1b);
-        nsA = rsA[t + 2]; nsB = rsB[t + 2];
+        if (FETCH) { nsA = symA_of(m2a); nsB = symB_of(m2b); fetch(t + 4, m2a, m2b); }
+        else { nsA = rsA[t + 2]; nsB = rsB[t + 2]; }
         __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads ahead of the step they overlap with
         step(HA, HB, w0a, w0b, t);
         __builtin_amdgcn_sched_barrier(0);
         load_scores(nsA, nsB, w0a, w0b);
-        nsA = rsA[t + 3]; nsB = rsB[t + 3];
+        if (FETCH) { nsA = symA_of(m3a); nsB = symB_of(m3b); fetch(t + 5, m3a, m3b); }
+        else { nsA = rsA[t + 3]; nsB = rsB[t + 3]; }
         __builtin_amdgcn_sched_barrier(0);
         step(HB, HA, w1a, w1b, t + 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -526,11 +547,11 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
                       pmx_record_t *d_out, hipStream_t stream, const int *n_dev = nullptr, uint32_t *tbuf = nullptr, int Tmax = 0)
 {
     constexpr bool PT = VAR == 6;
-    constexpr int EB = (VAR == 3 || VAR == 5 || VAR == 7 || PT) ? 1 : 2, WR = 4 / EB, RS = (R + WR - 1) / WR * WR;
+    constexpr int EB = (VAR == 3 || VAR == 5 || VAR == 7 || VAR == 8 || PT) ? 1 : 2, WR = 4 / EB, RS = (R + WR - 1) / WR * WR;
     constexpr int QP = G * RS, NP = 2 * (64 / G);
     if (NP * m.msize > 255) return 1;                 // per-pair pad symbol must fit a byte
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
-    const size_t lds = (PT ? (size_t)NP * ((G * R + 3) / 4 * 4) : (size_t)NP * m.msize * QP * EB + (size_t)QP * EB) + (size_t)NP * RP +
+    const size_t lds = (PT ? (size_t)NP * ((G * R + 3) / 4 * 4) : (size_t)NP * m.msize * QP * EB + (size_t)QP * EB) + (VAR == 8 ? 0 : (size_t)NP * RP) +
                        (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40 + 32;
     if (lds > 160 * 1024) return 1;
     { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_sw16_kernel<G, R, VAR>)); if (rc) return rc; }
@@ -623,11 +644,13 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
         const int rc = pmx_launch_sw16q(b, m, open, ext, d_out, stream, kernel_name);
         if (rc <= 0) return rc;
     }
+    const bool longref = b.max_rlen >= 1024 && !getenv("PMX_SW16_NO_FETCH");     // staged references would dominate the LDS
 #define TRY(GG, RR, NAME)                                                       \
     if (q <= (GG) * (RR)) {                                                     \
-        constexpr int R4 = (RR) % 4 == 0 ? (RR) : 4;                            \
-        const bool u8 = u8ok && (RR) % 4 == 0;                                  \
+        constexpr int R4 = (RR);            /* byte-profile rows are reserved in whole dwords: any R */ \
+        const bool u8 = u8ok;                                                   \
         int rc = pt ? launch_one<GG, RR, 6>(b, m, open, ext, d_out, stream)     \
+               : (u8 && sk && longref) ? launch_one<GG, R4, 8>(b, m, open, ext, d_out, stream)  \
                : (u8 && sk) ? launch_one<GG, R4, 5>(b, m, open, ext, d_out, stream)  \
                : u8 ? launch_one<GG, R4, 3>(b, m, open, ext, d_out, stream)     \
                : (var == 2 && sk) ? launch_one<GG, RR, 4>(b, m, open, ext, d_out, stream)  \

@@ -110,3 +110,6 @@ for _ in range(3): oncenw()
 e1.record(stream); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
 print("%-44s n=%-7d %8.1f GCUPS  (%.3f ms, %s)" % ("nw_striped_profile_16 300aa x ~4.75kaa BLOSUM62", n, 300 * int((roff[1:] - roff[:-1]).sum()) / ms / 1e6, ms, pkg.lib.pmx_last_kernel().decode()))
+# the same shapes with per-pair queries (no shared profile): LDS profiles per pair, reference symbols from HBM
+qt = np.tile(q, n); qto = np.arange(n + 1, dtype=np.int64) * 300
+run("sw_striped_16 300aa x ~4.75kaa per-pair queries", pkg.pmx_config_t(pkg.MODE_SW, 0, 11, 1, 16, 0, b62.inner), qt, qto, rbuf, roff, 300, 5000, reps=3)

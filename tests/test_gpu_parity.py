@@ -386,6 +386,22 @@ def test_sw16q_shared_query_protein_database_search(pkg, orc, qlen):
             and (got["end_ref"] == want[:, 2]).all() and (got["flags"] == 0).all()
 
 
+@pytest.mark.parametrize("alpha", ["dna", "protein"])
+def test_sw16_long_references_fetch_variant(pkg, orc, alpha):
+    """per-pair queries against long references: reference symbols come from HBM instead of LDS (VAR 8)"""
+    rng = np.random.default_rng(1700)
+    if alpha == "dna":
+        pm, om, al, go, ge = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3), DNA, 5, 2
+    else:
+        pm, om, al, go, ge = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt"), AA, 11, 1
+    for qlo, qhi, n in ((30, 160, 60), (200, 320, 40), (600, 1000, 16)):
+        qs = random_seqs(rng, n, qlo, qhi, al)
+        rs = [random_seqs(rng, 1, 1000, 4000, al)[0] + mutate(rng, q, 0.15, 0.04, al) + random_seqs(rng, 1, 100, 2500, al)[0] for q in qs]
+        rs[0] = rs[0][:1030]
+        _fast_case(pkg, orc, qs, rs, go, ge, pm, om)
+        assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_sw16_kernel")
+
+
 def test_sw16_saturating_int16_variant(pkg, orc):
     """scores too large for the max3 lanes (matrix max > 2048) take the saturating-int16 variant"""
     rng = np.random.default_rng(1450)
