@@ -953,7 +953,7 @@ extern "C" const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen,
     if (fast_sw_eligible(cfg) && cfg->matrix->size <= PMX_MAX_FAST_MSIZE && max_qlen <= 2048 && max_rlen <= 60000)
         return "pmx_sw16_kernel";
     if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && (cfg->want & ~PMX_WANT_SORTED) == 0 && cfg->width != 8 &&
-        cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && cfg->open >= cfg->extend && max_qlen < 2048 &&
+        cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && cfg->open >= cfg->extend && max_qlen <= 2048 &&
         cfg->matrix->size < PMX_MAX_FAST_MSIZE)
         return "pmx_nwsg16_kernel";
     if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && (cfg->want & ~PMX_WANT_SORTED) == PMX_WANT_STATS && cfg->width != 8 &&

@@ -1044,10 +1044,12 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
     if (b.max_rlen > 30000) return 1;
     const int q = b.max_qlen;
     // second-generation arithmetic (skewed columns, byte profile, VOP2) whenever its window holds
+    // (second generation, scores only: the row above lane 0 is a closed form, so no virtual row is needed and the
+    //  query may fill all G * R rows; the first generation and the traceback walk need row -1 to exist)
     if (const int nb = pmx_nwsgv_bias(b, m, open, ext)) {
         if (b.q_shared && !getenv("PMX_NWSG16_NO_SHARED")) {        // profile arm: one profile per workgroup, references from HBM
 #define TRYQ(GG, RR, NAME)                                                      \
-            if (q <= (GG) * (RR) - 1) {                                         \
+            if (q <= (GG) * (RR)) {                                         \
                 int rc = launch_nwsgq<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
                 if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; } \
             }
@@ -1061,7 +1063,7 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
         }
         const bool longref = b.max_rlen >= 1024 && !getenv("PMX_NWSG16_NO_FETCH");   // staged references would dominate the LDS
 #define TRYV(GG, RR, NAME)                                                      \
-        if (q <= (GG) * (RR) - 1) {                                             \
+        if (q <= (GG) * (RR)) {                                             \
             int rc = longref ? launch_nwsgv<GG, RR, false, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream) \
                              : launch_nwsgv<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
             if (rc <= 0) { if (kernel_name) *kernel_name = longref ? NAME "/fetch" : NAME; return rc; }   \

@@ -565,6 +565,25 @@ def test_nwsg16q_shared_query_profile_arm(pkg, orc, qlen):
         assert len(bad) == 0, (mode, sg, bad[:5], got[bad[:5]], want[bad[:5]])
 
 
+@pytest.mark.parametrize("qlen", [160, 256, 320, 512, 1024, 2048])
+def test_nwsg16_query_fills_every_row(pkg, orc, qlen):
+    """second generation, scores only: queries of exactly G * R rows (no virtual row on top), per-pair and shared"""
+    rng = np.random.default_rng(3500 + qlen)
+    pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    n = 2100 if qlen == 160 else 40
+    qs = random_seqs(rng, n, qlen, qlen, AA)
+    rs = [mutate(rng, q, 0.3, 0.05, AA) if i % 2 else random_seqs(rng, 1, 20, qlen + 100, AA)[0] for i, q in enumerate(qs)]
+    for mode, sg in ((0, None), (1, None), (1, orc.S1_BEG | orc.S2_BEG)):
+        _nwsg_case(pkg, orc, mode, sg, qs, rs, 11, 1, pm, om)
+        assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_nwsg16v_kernel")
+    q = qs[0]
+    qb, qo = orc.pack([q] * n); rb, ro = orc.pack(rs)
+    got = pkg.Aligner.new().global_().profile(pkg.Profile.new(q, False, pm)).matrix(pm).gap_open(11).gap_extend(1).solution_width(16).build().align_batch([], rs)
+    assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_nwsg16q_kernel")
+    want = orc.align_batch(0, qb, qo, rb, ro, 11, 1, om, bits=16)
+    assert (got["score"] == want[:, 0]).all() and (got["end_query"] == want[:, 1]).all() and (got["end_ref"] == want[:, 2]).all()
+
+
 def test_nwsg16_falls_back_outside_the_exact_window(pkg, orc):
     """long sequences with large penalties leave the biased 16-bit window: the general kernel takes over"""
     rng = np.random.default_rng(3300)
