@@ -1054,13 +1054,14 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         // rc == 1: shape not covered by the fast kernel -> general kernel below
     }
     if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&
-        dm.d.msize <= 8 && !q_shared && (n >= 2048 || getenv("PMX_STATS_BY_TRACE")) && !getenv("PMX_NO_STATS_BY_TRACE")) {
+        (dm.d.msize <= 8 || max_rlen <= 1024 || getenv("PMX_STATS_BY_TRACE_ANY")) && !q_shared && (n >= 2048 || getenv("PMX_STATS_BY_TRACE")) && !getenv("PMX_NO_STATS_BY_TRACE")) {
         // (a few pairs: the one-pass statistics kernel has the lower latency)
         // Small alphabets: statistics = counts along the traceback path (the same decisions and tie-breaks as the
         // coupled statistics tables).  The packed traceback sweep runs at more than twice the speed of the
         // statistics kernel and the walk is cheap; the trace scratch is bounded by working in chunks (same stream,
-        // no host synchronisation).  Large alphabets keep the statistics kernel: their LDS profiles would starve
-        // the 16-rows-per-lane traceback shapes of occupancy.
+        // no host synchronisation).  Large alphabets take this route for short references only (measured: per-pair
+        // protein 285 x 285, sw 0.37 -> 0.71 TCUPS, nw 0.40 -> 0.48; against 5-kaa references the staged references
+        // and per-pair profiles starve the 16-rows-per-lane traceback shapes and the statistics kernel wins).
         PmxBatch bt = b; bt.perm = nullptr;
         int variant = 0, Tmax = 0; size_t tbytes = 0;
         if (pmx_trace16_plan(bt, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes) == 0 && variant >= 10) {

@@ -854,6 +854,17 @@ def test_stats16p_packed_kernel_everywhere(pkg, orc, monkeypatch, gaps):
     _stats_case(pkg, orc, 0, None, q2, r2, gaps[0], gaps[1], pm, om)
 
 
+def test_stats_by_traceback_protein_short_references(pkg, orc):
+    """large alphabets, per-pair queries, short references, a full batch: statistics counted along the packed traceback"""
+    rng = np.random.default_rng(5400)
+    pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    qs = random_seqs(rng, 2100, 40, 200, AA)
+    rs = [mutate(rng, q, 0.3, 0.06, AA) if i % 3 else random_seqs(rng, 1, 10, 260, AA)[0] for i, q in enumerate(qs)]
+    for mode, sg in ((2, None), (0, None), (1, None), (1, orc.S1_BEG | orc.S2_END)):
+        _stats_case(pkg, orc, mode, sg, qs, rs, 11, 1, pm, om)
+        assert pkg.lib.pmx_last_kernel().decode().endswith("pmx_walk16_kernel/stats")
+
+
 def test_stats16_shared_query_blosum62(pkg, orc):
     """config 3 shape through the 4-wave shared-profile variant"""
     rng = np.random.default_rng(5200)
