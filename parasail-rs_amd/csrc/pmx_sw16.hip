@@ -644,6 +644,11 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
         const int rc = pmx_launch_sw16q(b, m, open, ext, d_out, stream, kernel_name);
         if (rc <= 0) return rc;
     }
+    // per-pair queries over a large alphabet: no LDS profile at all, the scores are read from the matrix (pmx_sw16m.hip)
+    if (!b.q_shared && var == 2 && u8ok && sk && !pt && (m.msize > 8 || getenv("PMX_SW16_MATRIX_LOOKUP")) && b.n > 2048) {
+        const int rc = pmx_launch_sw16m(b, m, open, ext, d_out, stream, kernel_name);
+        if (rc <= 0) return rc;
+    }
     const bool longref = b.max_rlen >= 1024 && !getenv("PMX_SW16_NO_FETCH");     // staged references would dominate the LDS
 #define TRY(GG, RR, NAME)                                                       \
     if (q <= (GG) * (RR)) {                                                     \

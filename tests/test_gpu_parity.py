@@ -402,6 +402,21 @@ def test_sw16_long_references_fetch_variant(pkg, orc, alpha):
         assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_sw16_kernel")
 
 
+@pytest.mark.parametrize("qhi,rhi", [(160, 400), (256, 300), (320, 1500), (512, 200), (1024, 120)])
+def test_sw16m_matrix_lookup_per_pair_protein(pkg, orc, qhi, rhi):
+    """per-pair protein batches (> 2048 pairs): no LDS profile, scores are read from the transposed matrix in LDS"""
+    rng = np.random.default_rng(1800 + qhi)
+    pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    n = 2100
+    qs = random_seqs(rng, n, max(1, qhi // 3), qhi, AA)
+    qs[0] = random_seqs(rng, 1, qhi, qhi, AA)[0]
+    rs = [mutate(rng, q, 0.3, 0.05, AA)[:rhi] if rng.random() < 0.5 else random_seqs(rng, 1, 5, rhi, AA)[0] for q in qs]
+    rs[3] = rs[3].lower(); qs[4] = qs[4][: len(qs[4]) // 2] + b"X*" + qs[4][len(qs[4]) // 2 + 2:]
+    _fast_case(pkg, orc, qs, rs, 11, 1, pm, om)
+    assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_sw16m_kernel")
+    _fast_case(pkg, orc, qs, rs, 11, 1, pm, om, width=0)
+
+
 def test_sw16_saturating_int16_variant(pkg, orc):
     """scores too large for the max3 lanes (matrix max > 2048) take the saturating-int16 variant"""
     rng = np.random.default_rng(1450)
