@@ -919,6 +919,249 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
     }
 }
 
+// Per-pair queries over a large alphabet (protein all-vs-all style batches): no LDS profile, the scores are byte reads
+// from the transposed matrix in LDS (see pmx_sw16m.hip); column msize of that matrix is the virtual row, row msize
+// the virtual / pad column, so the boundary scores of the second generation come out of the same lookup.
+template <int G, int R>
+__global__ __launch_bounds__(64)
+void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
+                        const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
+                        long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
+                        int msize, int open, int ext,
+                        int col_pen, int row_pen, int s1_end, int s2_end, int nb,
+                        const unsigned *__restrict__ perm,
+                        pmx_record_t *__restrict__ out)
+{
+    constexpr int QP = G * R;
+    constexpr int NPW = 2 * (64 / G);
+    constexpr int MSTR = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int lane = threadIdx.x;
+    const int g = lane % G, slotw = lane / G;
+    const int pA = 2 * slotw, pB = pA + 1;
+
+    // matT[r][q] (bytes): letters: score + open; column msize = a virtual row; row msize = the pad symbol (virtual column)
+    unsigned char *matT = lds;
+    unsigned char *map = lds + (msize + 1) * MSTR;
+    long long *ptab = reinterpret_cast<long long *>(map + 256);       // per pair: q offset, qlen, r offset, rlen, pair index
+    const int vrow_b = row_pen ? 0 : open, vcol_b = col_pen ? 0 : open;
+    const long long pair0 = (long long)blockIdx.x * NPW;
+    for (int i = lane; i < (msize + 1) * MSTR; i += 64) {
+        const int r = i / MSTR, q = i % MSTR;
+        int v;
+        if (r < msize) v = q < msize ? gmat[q * msize + r] + open : vrow_b;
+        else v = q < msize ? vcol_b : open;                           // virtual x virtual: score 0
+        matT[i] = (unsigned char)v;
+    }
+    for (int i = lane; i < 256; i += 64) map[i] = gmap[i];
+    if (lane < NPW) {
+        long long pos = pair0 + lane; if (pos >= n) pos = n - 1;
+        const long long pi = perm ? (long long)perm[pos] : pos;
+        const long long qb = qoff[pi], rb = roff[pi];
+        ptab[5 * lane + 0] = qb; ptab[5 * lane + 1] = qoff[pi + 1] - qb;
+        ptab[5 * lane + 2] = rb; ptab[5 * lane + 3] = roff[pi + 1] - rb;
+        ptab[5 * lane + 4] = (pair0 + lane < n) ? pi : -1;
+    }
+    __syncthreads();
+
+    const int qlA = (int)ptab[5 * pA + 1], qlB = (int)ptab[5 * pB + 1];
+    const int PvA = QP - qlA, PvB = QP - qlB;                         // virtual rows on top (query bottom-aligned)
+    const int rlA = (int)ptab[5 * pA + 3], rlB = (int)ptab[5 * pB + 3];
+    const uint8_t *refA = rbuf + ptab[5 * pA + 2], *refB = rbuf + ptab[5 * pB + 2];
+    int qa[R], qb_[R];                                                // LDS offsets of this lane's rows inside a matT row
+    {
+        const uint8_t *qA = qbuf + ptab[5 * pA + 0], *qB = qbuf + ptab[5 * pB + 0];
+        unsigned char ra[R], rb[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int er = g * R + k;
+            ra[k] = er >= PvA ? qA[er - PvA] : (unsigned char)0;
+            rb[k] = er >= PvB ? qB[er - PvB] : (unsigned char)0;
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int er = g * R + k;
+            qa[k] = er >= PvA ? (int)map[ra[k]] : msize;
+            qb_[k] = er >= PvB ? (int)map[rb[k]] : msize;
+        }
+    }
+    auto fetch = [&](int x, int &ra, int &rb) {
+        const int col = x - g;
+        ra = (col >= 0 && col < rlA) ? (int)refA[col] : -1;
+        rb = (col >= 0 && col < rlB) ? (int)refB[col] : -1;
+    };
+    auto sym_of = [&](int raw) -> int { return (raw < 0 ? msize : (int)map[raw]) * MSTR; };   // byte offset of the matT row
+
+    auto pack2 = [](int a, int b) -> int { return (a & 0xFFFF) | (b << 16); };
+    const int vExt = pack2(ext, ext), vC = pack2(open - ext, open - ext);
+    const v2us one2 = {1, 1};
+    const int base = nb + (G - g) * ext - open;
+    auto left_h = [&](int erow, int P) -> int { const int i = erow - P; return (i >= 0 && col_pen) ? -(open + i * ext) : 0; };
+    auto below_f = [&](int erow, int P) -> int { const int i = erow - P; return (i >= 0 && col_pen) ? -(open + i * ext) : -open; };
+
+    int X[R], E[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { X[k] = pack2(base + left_h(g * R + k, PvA), base + left_h(g * R + k, PvB)); E[k] = X[k]; }
+    int Hout = X[R - 1];
+    int Fout = pack2(base + open + below_f((g + 1) * R, PvA), base + open + below_f((g + 1) * R, PvB));
+    int diag0 = (g == 0) ? pack2(base, base) : pack2(base + left_h(g * R - 1, PvA), base + left_h(g * R - 1, PvB));
+    int topX = row_pen ? pack2(nb + (G + 1) * ext - 2 * open, nb + (G + 1) * ext - 2 * open)
+                       : pack2(nb + (G + 1) * ext - open, nb + (G + 1) * ext - open);
+    const int topStep = row_pen ? 0 : vExt;
+    int skewX = pack2((G - g + 1) * ext - open, (G - g + 1) * ext - open);
+
+    const v2s rl1 = PK(pack2(rlA - 1, rlB - 1)), rlv = PK(pack2(rlA, rlB));
+    int jj = ((-g) & 0xFFFF) * 0x00010001;
+    int res = 0;
+    v2s bestrow = PK(0); int bestrowj = 0;
+    v2s bestcol = PK(0); int bestcoli = 0;
+
+    int w[2][R];
+    auto load_scores = [&](int bsel, int rowA, int rowB) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int sa = matT[rowA + qa[k]], sb = matT[rowB + qb_[k]];
+            w[bsel][k] = sa | (sb << 16);
+        }
+    };
+    auto step = [&](int bsel) {
+        const int Hin = n_shift_up<G>(Hout, topX, g);
+        int F = n_shift_up<G>(Fout, topX, g);
+        int Tpre[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            Tpre[k] = ((k == 0) ? diag0 : X[k - 1]) + w[bsel][k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int Fe = F - vExt;
+            const int H = I32(n_max3f(PK(Tpre[k]), PK(E[k]), PK(Fe)));
+            const int Xn = H - vC;
+            E[k] = I32(n_max3f(PK(E[k]), PK(Xn), PK(Xn)));
+            F = I32(n_max3f(PK(Fe), PK(Xn), PK(Xn)));
+            X[k] = Xn;
+        }
+        diag0 = Hin;
+        Hout = X[R - 1];
+        Fout = F;
+        // ---- captures (as in pmx_nwsg16v_kernel) ----
+        const v2s jv = PK(jj);
+        const int mLast = m_eq(jv, rl1);
+        res = n_bfi(mLast, Hout, res);
+        if (s2_end) {
+            const v2s cand = PK(I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, Hout) - __builtin_bit_cast(v2us, skewX))));
+            const int imp = m_lt(bestrow, cand) & m_ult(jv, rlv);
+            bestrow = PK(n_bfi(imp, I32(cand), I32(bestrow)));
+            bestrowj = n_bfi(imp, jj, bestrowj);
+        }
+        if (s1_end && __builtin_amdgcn_ballot_w64(mLast != 0) != 0) {
+            v2s cm = PK(0); int krow = 0;
+            v2s vals[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int er = g * R + k;
+                const int mreal = ~m_lt(PK(pack2(er, er)), PK(pack2(PvA, PvB)));
+                vals[k] = PK(X[k] & mreal);
+                cm = n_max3f(cm, vals[k], vals[k]);
+            }
+#pragma unroll
+            for (int k = R - 1; k >= 0; --k) {
+                const int er = g * R + k;
+                krow = n_bfi(m_eq(vals[k], cm), pack2(er, er), krow);
+            }
+            const int imp = m_lt(bestcol, cm) & mLast;
+            bestcol = PK(n_bfi(imp, I32(cm), I32(bestcol)));
+            bestcoli = n_bfi(imp, krow, bestcoli);
+        }
+        jj = I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, jj) + one2));
+        skewX = I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, skewX) + __builtin_bit_cast(v2us, vExt)));
+        topX += topStep;
+    };
+
+    int max_rlen = 0;
+#pragma unroll
+    for (int p = 0; p < NPW; ++p) max_rlen = max(max_rlen, (int)ptab[5 * p + 3]);
+    const int T = (max_rlen + G - 1 + 1) & ~1;
+    int r0a, r0b, r1a, r1b, m2a, m2b, m3a, m3b;
+    fetch(0, r0a, r0b); fetch(1, r1a, r1b); fetch(2, m2a, m2b); fetch(3, m3a, m3b);
+    load_scores(0, sym_of(r0a), sym_of(r0b));
+    int nsA = sym_of(r1a), nsB = sym_of(r1b);
+    for (int t = 0; t < T; t += 2) {
+        load_scores(1, nsA, nsB);
+        nsA = sym_of(m2a); nsB = sym_of(m2b);
+        fetch(t + 4, m2a, m2b);
+        __builtin_amdgcn_sched_barrier(0);
+        step(0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_scores(0, nsA, nsB);
+        nsA = sym_of(m3a); nsB = sym_of(m3b);
+        fetch(t + 5, m3a, m3b);
+        __builtin_amdgcn_sched_barrier(0);
+        step(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    unsigned keyA = ((unsigned)(I32(bestcol) & 0xFFFF) << 16) | (0xFFFFu - (unsigned)(bestcoli & 0xFFFF));
+    unsigned keyB = ((unsigned)((unsigned)I32(bestcol) >> 16) << 16) | (0xFFFFu - ((unsigned)bestcoli >> 16));
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) {
+        const unsigned oa = __shfl_xor(keyA, off, 64), ob = __shfl_xor(keyB, off, 64);
+        keyA = oa > keyA ? oa : keyA;
+        keyB = ob > keyB ? ob : keyB;
+    }
+    const int lastlane = slotw * G + G - 1;
+    const int resL = __shfl(res, lastlane, 64);
+    const int browL = __shfl(I32(bestrow), lastlane, 64), browjL = __shfl(bestrowj, lastlane, 64);
+    if (g == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long pi = ptab[5 * (h ? pB : pA) + 4];
+            if (pi >= 0) {
+                const int ql = h ? qlB : qlA, rl = h ? rlB : rlA, P = h ? PvB : PvA;
+                const int unsk = nb + (rl - 1 + G) * ext - open + ext;
+                const int corner = (int)(h ? ((unsigned)resL >> 16) : (resL & 0xFFFF)) - unsk;
+                pmx_record_t rec;
+                rec.flags = 0;
+                if (!s1_end && !s2_end) { rec.score = corner; rec.end_query = ql - 1; rec.end_ref = rl - 1; }
+                else {
+                    int best = -2147483647 - 1, ei = 0, ej = 0;
+                    if (s2_end) {
+                        best = (int)(h ? ((unsigned)browL >> 16) : (browL & 0xFFFF)) - nb;
+                        ei = ql - 1; ej = (int)(h ? ((unsigned)browjL >> 16) : (browjL & 0xFFFF));
+                    }
+                    if (s1_end) {
+                        const unsigned key = h ? keyB : keyA;
+                        const int cv = (int)(key >> 16) - unsk;
+                        if (cv > best) { best = cv; ei = (int)(0xFFFFu - (key & 0xFFFFu)) - P; ej = rl - 1; }
+                    }
+                    rec.score = best; rec.end_query = ei; rec.end_ref = ej;
+                }
+                out[pi] = rec;
+            }
+        }
+    }
+}
+
+template <int G, int R>
+static int launch_nwsgm(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
+                        pmx_record_t *d_out, hipStream_t stream)
+{
+    constexpr int NP = 2 * (64 / G);
+    const size_t lds = (size_t)(m.msize + 1) * 32 + 256 + (size_t)NP * 40;
+    const bool sg = mode == PMX_MODE_SG;
+    const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
+    const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
+    const long long blocks = (b.n + NP - 1) / NP;
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL((pmx_nwsg16m_kernel<G, R>), dim3((unsigned)blocks), dim3(64), lds, stream,
+                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper, m.msize, open, ext,
+                       col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
 template <int G, int R>
 static int launch_nwsgq(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
                         pmx_record_t *d_out, hipStream_t stream)
@@ -1060,6 +1303,19 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
             TRYQ(64, 16, "pmx_nwsg16q_kernel<64,16>/shared profile")
             TRYQ(64, 32, "pmx_nwsg16q_kernel<64,32>/shared profile")
 #undef TRYQ
+        }
+        if (!b.q_shared && m.msize > 8 && m.msize < 32 && b.n > 2048 && !getenv("PMX_NWSG16_NO_MATRIX_LOOKUP")) {   // per-pair, large alphabet
+#define TRYM(GG, RR, NAME)                                                      \
+            if (q <= (GG) * (RR)) {                                             \
+                int rc = launch_nwsgm<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
+                if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; } \
+            }
+            TRYM(16, 10, "pmx_nwsg16m_kernel<16,10>/matrix lookup")
+            TRYM(16, 16, "pmx_nwsg16m_kernel<16,16>/matrix lookup")
+            TRYM(32, 10, "pmx_nwsg16m_kernel<32,10>/matrix lookup")
+            TRYM(32, 16, "pmx_nwsg16m_kernel<32,16>/matrix lookup")
+            TRYM(64, 16, "pmx_nwsg16m_kernel<64,16>/matrix lookup")
+#undef TRYM
         }
         const bool longref = b.max_rlen >= 1024 && !getenv("PMX_NWSG16_NO_FETCH");   // staged references would dominate the LDS
 #define TRYV(GG, RR, NAME)                                                      \

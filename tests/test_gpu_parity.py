@@ -590,13 +590,27 @@ def test_nwsg16_query_fills_every_row(pkg, orc, qlen):
     rs = [mutate(rng, q, 0.3, 0.05, AA) if i % 2 else random_seqs(rng, 1, 20, qlen + 100, AA)[0] for i, q in enumerate(qs)]
     for mode, sg in ((0, None), (1, None), (1, orc.S1_BEG | orc.S2_BEG)):
         _nwsg_case(pkg, orc, mode, sg, qs, rs, 11, 1, pm, om)
-        assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_nwsg16v_kernel")
+        assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_nwsg16m_kernel" if n > 2048 else "pmx_nwsg16v_kernel")
     q = qs[0]
     qb, qo = orc.pack([q] * n); rb, ro = orc.pack(rs)
     got = pkg.Aligner.new().global_().profile(pkg.Profile.new(q, False, pm)).matrix(pm).gap_open(11).gap_extend(1).solution_width(16).build().align_batch([], rs)
     assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_nwsg16q_kernel")
     want = orc.align_batch(0, qb, qo, rb, ro, 11, 1, om, bits=16)
     assert (got["score"] == want[:, 0]).all() and (got["end_query"] == want[:, 1]).all() and (got["end_ref"] == want[:, 2]).all()
+
+
+@pytest.mark.parametrize("qhi,rhi", [(159, 300), (256, 256), (320, 1400), (500, 200), (1024, 100)])
+def test_nwsg16m_matrix_lookup_per_pair_protein(pkg, orc, qhi, rhi):
+    """global / semi-global, per-pair protein batches (> 2048 pairs): scores read from the transposed matrix in LDS"""
+    rng = np.random.default_rng(3600 + qhi)
+    pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    n = 2100
+    qs = random_seqs(rng, n, max(1, qhi // 3), qhi, AA)
+    qs[0] = random_seqs(rng, 1, qhi, qhi, AA)[0]
+    rs = [mutate(rng, q, 0.3, 0.05, AA)[:rhi] if rng.random() < 0.5 else random_seqs(rng, 1, 5, rhi, AA)[0] for q in qs]
+    for mode, sg in ((0, None), (1, None), (1, orc.S1_BEG | orc.S2_END), (1, orc.S1_END | orc.S2_BEG), (1, orc.S2_BEG | orc.S2_END)):
+        _nwsg_case(pkg, orc, mode, sg, qs, rs, 11, 1, pm, om)
+        assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_nwsg16m_kernel")
 
 
 def test_nwsg16_falls_back_outside_the_exact_window(pkg, orc):
