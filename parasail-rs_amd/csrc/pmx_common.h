@@ -65,6 +65,9 @@ int pmx_launch_sw16q(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext
 int pmx_launch_sw16m(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                      pmx_record_t *d_out, hipStream_t stream, const char **kernel_name);
 
+int pmx_launch_sw16m_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
+                           pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream);
+
 // Length-sorted processing order for ragged batches (pmx_sort.hip).
 size_t pmx_sort_scratch_bytes(long long n);
 int pmx_build_length_perm(const int64_t *d_roff, long long n, void *scratch, const unsigned **perm_out, hipStream_t stream);

@@ -590,6 +590,14 @@ static bool sw16_trace_ok(const PmxBatch &b, const PmxDevMatrix &m, int open, in
 int pmx_sw16_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, int *variant, int *Tmax, size_t *trace_bytes)
 {
     if (!sw16_trace_ok(b, m, open, ext)) return 1;
+    if (m.msize > 8 && m.msize < 32 && !getenv("PMX_SW16_NO_MATRIX_LOOKUP")) {     // large alphabet: the matrix-lookup kernel (no profile, 1 KB of LDS)
+        int G = 0;
+        for (int v = 1; v < 4 && !G; ++v) if (b.max_qlen <= (8 << v) * 16) { *variant = 4 + v; G = 8 << v; }
+        if (!G) return 1;
+        *Tmax = (b.max_rlen + G - 1 + 1) & ~1;          // that kernel sweeps an even number of steps
+        *trace_bytes = (size_t)((b.n + 2 * (64 / G) - 1) / (2 * (64 / G))) * (size_t)*Tmax * 64 * 16;
+        return 0;
+    }
     int G = 0;
     for (int v = 0; v < 4 && !G; ++v) {                  // the first shape that holds the query, whose per-pair pad symbols fit a
         const int g = 8 << v, np = 2 * (64 / g);         // byte and whose profiles fit the LDS (the launcher's own conditions)
@@ -607,6 +615,7 @@ int pmx_launch_sw16_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m,
                           pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream)
 {
     if (!sw16_trace_ok(b, m, open, ext)) return 1;
+    if (variant >= 4) return pmx_launch_sw16m_trace(variant - 4, b, m, open, ext, d_out, tbuf, Tmax, stream);
     switch (variant) {
     case 0: return launch_one<8, 16, 7>(b, m, open, ext, d_out, stream, nullptr, tbuf, Tmax);
     case 1: return launch_one<16, 16, 7>(b, m, open, ext, d_out, stream, nullptr, tbuf, Tmax);

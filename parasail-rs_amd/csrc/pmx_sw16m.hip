@@ -41,7 +41,8 @@ __device__ __forceinline__ int m_shift_up(int x, int neutral, int g)
     }
 }
 
-template <int G, int R>
+// TR: also writes the 4-bit traceback cells (bits and layout of pmx_nwsg16v_kernel<..,true>; rows top-aligned).
+template <int G, int R, bool TR>
 __global__ __launch_bounds__(64)
 void pmx_sw16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                       const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
@@ -49,8 +50,9 @@ void pmx_sw16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
                       int msize, int open, int ext,
                       int limit /* biased scores at or above this are flagged for a re-run (skew growth already taken off) */,
                       int sat_above, const unsigned *__restrict__ perm,
-                      pmx_record_t *__restrict__ out)
+                      pmx_record_t *__restrict__ out, uint32_t *__restrict__ tbuf, int Tmax)
 {
+    static_assert(!TR || R == 16, "trace: four packed planes of 4 rows");
     constexpr int NPW = 2 * (64 / G);           // pairs per wave = pairs per workgroup
     constexpr int MSTR = 32;                    // bytes per row of the transposed matrix
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -129,6 +131,15 @@ void pmx_sw16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
             w[bsel][k] = sa | (sb << 16);
         }
     };
+    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * Tmax) * 256 + lane * 4 : nullptr;
+    auto push = [&](int &pl, int a, int b) {          // pl = 2 * pl + (a < b), per half
+        typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+        const u2 fifteen = {15, 15};
+        const int bit = M_I32(__builtin_bit_cast(m_v2s, __builtin_bit_cast(u2, M_PK(a) - M_PK(b)) >> fifteen));
+        int r;
+        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(pl), "v"(0x00020002), "v"(bit));
+        pl = r;
+    };
     auto step = [&](int bsel, int t) {
         const int Hin = m_shift_up<G>(Hout, Zv - vOpen, g);
         int F = m_shift_up<G>(Fout, Zv, g);
@@ -139,16 +150,35 @@ void pmx_sw16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
         }
         __builtin_amdgcn_sched_barrier(0);
         int colmax = 0;
+        int plane[TR ? R / 4 : 1];
+        if (TR) {
+#pragma unroll
+            for (int x = 0; x < R / 4; ++x) plane[x] = 0;
+        }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int Fe = F - vExt;
             const int H = m_max3(T[k], E[k], Fe);
             const int Xn = H - vC;
+            if (TR) {
+                push(plane[k / 4], T[k], H);         // ND
+                push(plane[k / 4], Fe, H);           // NDL
+                push(plane[k / 4], E[k], Xn);        // EO
+                push(plane[k / 4], Fe, Xn);          // FO
+            }
             E[k] = m_max3(E[k], Xn, Xn);
             F = m_max3(Fe, Xn, Zv);
             X[k] = Xn;
             if (k & 1) colmax = (k == 1) ? m_max3(X[0], Xn, Xn) : m_max3(colmax, X[k - 1], Xn);
             else if (k == R - 1) colmax = m_max3(colmax, Xn, Xn);
+        }
+        if (TR) {
+            uint4 w4;
+            w4.x = __builtin_amdgcn_perm(plane[0], plane[1], 0x05040100);
+            w4.y = __builtin_amdgcn_perm(plane[2], plane[3], 0x05040100);
+            w4.z = __builtin_amdgcn_perm(plane[0], plane[1], 0x07060302);
+            w4.w = __builtin_amdgcn_perm(plane[2], plane[3], 0x07060302);
+            *reinterpret_cast<uint4 *>(tw + (size_t)t * 256) = w4;
         }
         diag0 = Hin;
         Hout = X[R - 1];
@@ -233,18 +263,31 @@ void pmx_sw16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
     }
 }
 
-template <int G, int R>
-static int launch_m(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, pmx_record_t *d_out, hipStream_t stream)
+template <int G, int R, bool TR = false>
+static int launch_m(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, pmx_record_t *d_out, hipStream_t stream,
+                    uint32_t *tbuf = nullptr, int Tmax = 0)
 {
     constexpr int NP = 2 * (64 / G);
     const size_t lds = (size_t)(m.msize + 1) * 32 + 256 + (size_t)NP * 40;
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL((pmx_sw16m_kernel<G, R>), dim3((unsigned)blocks), dim3(64), lds, stream,
+    hipLaunchKernelGGL((pmx_sw16m_kernel<G, R, TR>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper, m.msize, open, ext,
-                       M_LIMITx(m.max) - (b.max_rlen + 2 * G + 4) * ext, b.sat_above > 0 ? b.sat_above : 2147483647, b.perm, d_out);
+                       M_LIMITx(m.max) - (b.max_rlen + 2 * G + 4) * ext, b.sat_above > 0 ? b.sat_above : 2147483647, b.perm, d_out, tbuf, Tmax);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
+}
+
+// traceback variant, lane groups of 16 / 32 / 64 (variant 1..3 of pmx_sw16_trace_plan)
+int pmx_launch_sw16m_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
+                           pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream)
+{
+    switch (variant) {
+    case 1: return launch_m<16, 16, true>(b, m, open, ext, d_out, stream, tbuf, Tmax);
+    case 2: return launch_m<32, 16, true>(b, m, open, ext, d_out, stream, tbuf, Tmax);
+    case 3: return launch_m<64, 16, true>(b, m, open, ext, d_out, stream, tbuf, Tmax);
+    }
+    return 1;
 }
 
 // 0 launched, 1 not eligible (the caller goes on with pmx_sw16's own variants), <0 HIP error.

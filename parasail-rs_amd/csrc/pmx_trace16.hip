@@ -491,7 +491,7 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
                   hipLaunchKernelGGL((pmx_walk16_kernel<GG, 16, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 2 * (size_t)stage, stream, \
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage, top, stats_out, row_pen_, col_pen_,     \
                        (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg)
-        switch (variant % 10) {
+        switch ((variant % 10) & 3) {          // lane-group size: 8, 16, 32, 64 (variants 4..7 are the matrix-lookup kernels)
         case 0: WALKP(8); break;
         case 1: WALKP(16); break;
         case 2: WALKP(32); break;
