@@ -922,7 +922,7 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
 // Per-pair queries over a large alphabet (protein all-vs-all style batches): no LDS profile, the scores are byte reads
 // from the transposed matrix in LDS (see pmx_sw16m.hip); column msize of that matrix is the virtual row, row msize
 // the virtual / pad column, so the boundary scores of the second generation come out of the same lookup.
-template <int G, int R>
+template <int G, int R, bool TR>
 __global__ __launch_bounds__(64)
 void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                         const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
@@ -930,8 +930,9 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
                         int msize, int open, int ext,
                         int col_pen, int row_pen, int s1_end, int s2_end, int nb,
                         const unsigned *__restrict__ perm,
-                        pmx_record_t *__restrict__ out)
+                        pmx_record_t *__restrict__ out, uint32_t *__restrict__ tbuf, int Tmax)
 {
+    static_assert(!TR || R == 16, "trace: four packed planes of 4 rows");
     constexpr int QP = G * R;
     constexpr int NPW = 2 * (64 / G);
     constexpr int MSTR = 32;
@@ -1025,7 +1026,15 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             w[bsel][k] = sa | (sb << 16);
         }
     };
-    auto step = [&](int bsel) {
+    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * Tmax) * 256 + lane * 4 : nullptr;
+    auto push = [&](int &pl, int a, int b) {          // pl = 2 * pl + (a < b), per half
+        const v2us fifteen = {15, 15};
+        const int bit = I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, PK(a) - PK(b)) >> fifteen));
+        int r;
+        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(pl), "v"(0x00020002), "v"(bit));
+        pl = r;
+    };
+    auto step = [&](int bsel, int t) {
         const int Hin = n_shift_up<G>(Hout, topX, g);
         int F = n_shift_up<G>(Fout, topX, g);
         int Tpre[R];
@@ -1034,14 +1043,33 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             Tpre[k] = ((k == 0) ? diag0 : X[k - 1]) + w[bsel][k];
         }
         __builtin_amdgcn_sched_barrier(0);
+        int plane[TR ? R / 4 : 1];
+        if (TR) {
+#pragma unroll
+            for (int x = 0; x < R / 4; ++x) plane[x] = 0;
+        }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int Fe = F - vExt;
             const int H = I32(n_max3f(PK(Tpre[k]), PK(E[k]), PK(Fe)));
             const int Xn = H - vC;
+            if (TR) {
+                push(plane[k / 4], Tpre[k], H);      // ND
+                push(plane[k / 4], Fe, H);           // NDL
+                push(plane[k / 4], E[k], Xn);        // EO
+                push(plane[k / 4], Fe, Xn);          // FO
+            }
             E[k] = I32(n_max3f(PK(E[k]), PK(Xn), PK(Xn)));
             F = I32(n_max3f(PK(Fe), PK(Xn), PK(Xn)));
             X[k] = Xn;
+        }
+        if (TR) {
+            uint4 w4;
+            w4.x = __builtin_amdgcn_perm(plane[0], plane[1], 0x05040100);
+            w4.y = __builtin_amdgcn_perm(plane[2], plane[3], 0x05040100);
+            w4.z = __builtin_amdgcn_perm(plane[0], plane[1], 0x07060302);
+            w4.w = __builtin_amdgcn_perm(plane[2], plane[3], 0x07060302);
+            *reinterpret_cast<uint4 *>(tw + (size_t)t * 256) = w4;
         }
         diag0 = Hin;
         Hout = X[R - 1];
@@ -1093,13 +1121,13 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         nsA = sym_of(m2a); nsB = sym_of(m2b);
         fetch(t + 4, m2a, m2b);
         __builtin_amdgcn_sched_barrier(0);
-        step(0);
+        step(0, t);
         __builtin_amdgcn_sched_barrier(0);
         load_scores(0, nsA, nsB);
         nsA = sym_of(m3a); nsB = sym_of(m3b);
         fetch(t + 5, m3a, m3b);
         __builtin_amdgcn_sched_barrier(0);
-        step(1);
+        step(1, t + 1);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -1144,9 +1172,9 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     }
 }
 
-template <int G, int R>
+template <int G, int R, bool TR = false>
 static int launch_nwsgm(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
-                        pmx_record_t *d_out, hipStream_t stream)
+                        pmx_record_t *d_out, hipStream_t stream, uint32_t *tbuf = nullptr, int Tmax = 0)
 {
     constexpr int NP = 2 * (64 / G);
     const size_t lds = (size_t)(m.msize + 1) * 32 + 256 + (size_t)NP * 40;
@@ -1155,9 +1183,9 @@ static int launch_nwsgm(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL((pmx_nwsg16m_kernel<G, R>), dim3((unsigned)blocks), dim3(64), lds, stream,
+    hipLaunchKernelGGL((pmx_nwsg16m_kernel<G, R, TR>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper, m.msize, open, ext,
-                       col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out);
+                       col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
@@ -1248,6 +1276,14 @@ int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
 {
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
     if (b.q_shared || b.perm || !pmx_nwsgv_bias(b, m, open, ext)) return 1;
+    if (m.msize > 8 && m.msize < 32 && !getenv("PMX_NWSG16_NO_MATRIX_LOOKUP")) {   // large alphabet: the matrix-lookup kernel (1 KB of LDS)
+        int G = 0;
+        for (int v = 1; v < 4 && !G; ++v) if (b.max_qlen <= (8 << v) * 16 - 1) { *variant = 4 + v; G = 8 << v; }
+        if (!G) return 1;
+        *Tmax = (b.max_rlen + G - 1 + 1) & ~1;
+        *trace_bytes = (size_t)((b.n + 2 * (64 / G) - 1) / (2 * (64 / G))) * (size_t)*Tmax * 64 * 16;
+        return 0;
+    }
     int G = 0;
     for (int v = 0; v < 4 && !G; ++v) {                  // the first shape that holds the query and fits the LDS (launch_nwsgv's condition)
         const int g = 8 << v, np = 2 * (64 / g);
@@ -1268,6 +1304,9 @@ int pmx_launch_nwsgv_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m
     const int nb = pmx_nwsgv_bias(b, m, open, ext);
     if (!nb) return 1;
     switch (variant) {
+    case 5: return launch_nwsgm<16, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 6: return launch_nwsgm<32, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 7: return launch_nwsgm<64, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 0: return launch_nwsgv<8, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 1: return launch_nwsgv<16, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 2: return launch_nwsgv<32, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
