@@ -1060,7 +1060,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         // coupled statistics tables).  The packed traceback sweep runs at more than twice the speed of the
         // statistics kernel and the walk is cheap; the trace scratch is bounded by working in chunks (same stream,
         // no host synchronisation).  Large alphabets take this route for short references only (measured: per-pair
-        // protein 285 x 285, sw 0.37 -> 0.71 TCUPS, nw 0.40 -> 0.48; against 5-kaa references the staged references
+        // protein 285 x 285, sw 0.37 -> 1.03 TCUPS, nw 0.40 -> 0.89 with the matrix-lookup traceback kernels; against 5-kaa references the staged references
         // and per-pair profiles starve the 16-rows-per-lane traceback shapes and the statistics kernel wins).
         PmxBatch bt = b; bt.perm = nullptr;
         int variant = 0, Tmax = 0; size_t tbytes = 0;
