@@ -1364,7 +1364,9 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
             if (rc <= 0) { if (kernel_name) *kernel_name = longref ? NAME "/fetch" : NAME; return rc; }   \
         }
         if (b.n > 2048) {       // (few pairs: latency counts, the 16-lane shapes have half the work per step)
-            TRYV(8, 13, "pmx_nwsg16v_kernel<8,13>")      // reads of 100 / 125 / 150 bp: few padding rows
+            TRYV(8, 7, "pmx_nwsg16v_kernel<8,7>")        // reads of 50 / 75 / 100 / 125 / 150 bp: few padding rows
+            TRYV(8, 10, "pmx_nwsg16v_kernel<8,10>")
+            TRYV(8, 13, "pmx_nwsg16v_kernel<8,13>")
             TRYV(8, 16, "pmx_nwsg16v_kernel<8,16>")
             TRYV(8, 19, "pmx_nwsg16v_kernel<8,19>")
             TRYV(8, 20, "pmx_nwsg16v_kernel<8,20>")

@@ -682,7 +682,7 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
         if (rc <= 0) { if (kernel_name) *kernel_name = pt ? "pmx_sw16_kernel<8," #RR ">/max3+vop2+skew+permtable" : sk ? "pmx_sw16_kernel<8," #RR ">/max3+vop2+u8+skew" : "pmx_sw16_kernel<8," #RR ">/max3+vop2+u8"; return rc; } \
     }
     // (a handful of pairs cannot fill the chip: then latency counts, and the 16-lane shape has half the work per step)
-    if (b.n > 2048) { TRY8(13) TRY8(16) TRY8(19) TRY8(20) }
+    if (b.n > 2048) { TRY8(7) TRY8(10) TRY8(13) TRY8(16) TRY8(19) TRY8(20) }      // 50 / 75 / 100 / 125 / 150 bp reads
 #undef TRY8
     TRY(16, 10, "pmx_sw16_kernel<16,10>")
     TRY(16, 16, "pmx_sw16_kernel<16,16>")

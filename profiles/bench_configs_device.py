@@ -113,3 +113,9 @@ print("%-44s n=%-7d %8.1f GCUPS  (%.3f ms, %s)" % ("nw_striped_profile_16 300aa 
 # the same shapes with per-pair queries (no shared profile): LDS profiles per pair, reference symbols from HBM
 qt = np.tile(q, n); qto = np.arange(n + 1, dtype=np.int64) * 300
 run("sw_striped_16 300aa x ~4.75kaa per-pair queries", pkg.pmx_config_t(pkg.MODE_SW, 0, 11, 1, 16, 0, b62.inner), qt, qto, rbuf, roff, 300, 5000, reps=3)
+# shorter reads, local
+for L in (50, 75, 100):
+    n = 1000000
+    qbuf = DNA[rng.integers(0, 4, size=n * L)]; qoff = np.arange(n + 1, dtype=np.int64) * L
+    rbuf = DNA[rng.integers(0, 4, size=n * L)]; roff = qoff.copy()
+    run("sw_striped_16 %dx%d" % (L, L), pkg.pmx_config_t(pkg.MODE_SW, 0, 5, 2, 16, 0, dna.inner), qbuf, qoff, rbuf, roff, L, L)

@@ -287,7 +287,7 @@ def test_sw16_every_arithmetic_variant(pkg, orc, monkeypatch, env):
     _fast_case(pkg, orc, qs, rs, 11, 1, bm, bo)
 
 
-@pytest.mark.parametrize("qmax", [100, 128, 150, 160])
+@pytest.mark.parametrize("qmax", [36, 50, 56, 75, 80, 100, 128, 150, 160])
 def test_sw16_permtable_variant_and_wildcard_retry(pkg, orc, qmax):
     """batches of >= 4096 short DNA pairs take the perm-table kernel; pairs with a wildcard in the query are
     handed back on the device and redone with the LDS profile (no flag may leak out)"""
@@ -533,7 +533,7 @@ def test_nwsg16_first_generation_kernel(pkg, orc, monkeypatch):
     _nwsg_case(pkg, orc, 0, None, qs, rs, 5, 2, pm, om)
 
 
-@pytest.mark.parametrize("qmax", [100, 103, 127, 151, 159])
+@pytest.mark.parametrize("qmax", [36, 50, 56, 75, 80, 100, 103, 127, 151, 159])
 def test_nwsg16_eight_lane_shapes(pkg, orc, qmax):
     """the 8-lane shapes <8,13> <8,16> <8,19> <8,20> of the second-generation kernel (batches above 2048 pairs)"""
     rng = np.random.default_rng(3270 + qmax)
