@@ -1053,45 +1053,53 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         }
         // rc == 1: shape not covered by the fast kernel -> general kernel below
     }
-    if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&
-        (dm.d.msize <= 8 || max_rlen <= 1024 || getenv("PMX_STATS_BY_TRACE_ANY")) && !q_shared && (n >= 2048 || getenv("PMX_STATS_BY_TRACE")) && !getenv("PMX_NO_STATS_BY_TRACE")) {
-        // (a few pairs: the one-pass statistics kernel has the lower latency)
-        // Small alphabets: statistics = counts along the traceback path (the same decisions and tie-breaks as the
-        // coupled statistics tables).  The packed traceback sweep runs at more than twice the speed of the
-        // statistics kernel and the walk is cheap; the trace scratch is bounded by working in chunks (same stream,
-        // no host synchronisation).  Large alphabets take this route for short references only (measured: per-pair
-        // protein 285 x 285, sw 0.37 -> 1.03 TCUPS, nw 0.40 -> 0.89 with the matrix-lookup traceback kernels; against 5-kaa references the staged references
-        // and per-pair profiles starve the 16-rows-per-lane traceback shapes and the statistics kernel wins).
-        PmxBatch bt = b; bt.perm = nullptr;
-        int variant = 0, Tmax = 0; size_t tbytes = 0;
-        if (pmx_trace16_plan(bt, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes) == 0 && variant >= 10) {
-            double budget = 8e9;
-            { size_t fb = 0, tb = 0; if (hipMemGetInfo(&fb, &tb) == hipSuccess && 0.3 * (double)fb < budget) budget = 0.3 * (double)fb; }
-            const double per_pair = (double)tbytes / (double)n + 1.0;
-            int64_t chunk = (int64_t)(budget / per_pair) / 64 * 64;
-            if (chunk < 64) chunk = 64;
-            if (chunk > n) chunk = n;
-            bt.n = chunk;
-            (void)pmx_trace16_plan(bt, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes);
-            uint32_t *tbuf = nullptr;
-            if (scratch_reserve(tbytes, (void **)&tbuf, SCR_TRACE)) return -1;
-            for (int64_t c0 = 0; c0 < n; c0 += chunk) {
-                PmxBatch bc = bt;
-                bc.n = (n - c0 < chunk) ? n - c0 : chunk;
-                bc.qoff = d_qoff + c0; bc.roff = d_roff + c0;
-                const int rc = pmx_launch_trace16(variant, bc, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out + c0, tbuf, Tmax,
-                                                  nullptr, nullptr, nullptr, nullptr, st, d_stats_out + c0);
-                if (rc) { set_err("stats-by-traceback launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    // statistics: (0) small alphabets in full batches: counts along the packed traceback; (1) the packed statistics kernel
+    // (shared profile, or per-pair over a large alphabet, no free end); (2) large alphabets with short references: traceback
+    // again; (3) the unpacked statistics kernel
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
+                // second generation (two pairs per lane slot); global / semi-global inside its exact window
+                const int rc = pmx_launch_stats16p(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, d_stats_out, st, &g_last_kernel);
+                if (rc < 0) { set_err("stats16p launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
+                if (rc == 0) return 0;
             }
-            g_last_kernel = variant >= 20 ? "pmx_sw16_kernel/packed trace + pmx_walk16_kernel/stats" : "pmx_nwsg16v_kernel/packed trace + pmx_walk16_kernel/stats";
-            return 0;
+            if (!(dm.d.msize > 8 && (max_rlen <= 1024 || getenv("PMX_STATS_BY_TRACE_ANY")))) break;
         }
-    }
-    if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
-        // second generation (two pairs per lane slot); global / semi-global inside its exact window
-        const int rc = pmx_launch_stats16p(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, d_stats_out, st, &g_last_kernel);
-        if (rc < 0) { set_err("stats16p launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
-        if (rc == 0) return 0;
+        if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&
+            (dm.d.msize <= 8 || pass == 1) && !q_shared && (n >= 2048 || getenv("PMX_STATS_BY_TRACE")) && !getenv("PMX_NO_STATS_BY_TRACE")) {
+            // (a few pairs: the one-pass statistics kernel has the lower latency)
+            // Small alphabets: statistics = counts along the traceback path (the same decisions and tie-breaks as the
+            // coupled statistics tables).  The packed traceback sweep runs at more than twice the speed of the
+            // statistics kernel and the walk is cheap; the trace scratch is bounded by working in chunks (same stream,
+            // no host synchronisation).  Large alphabets take this route for short references only (measured: per-pair
+            // protein 285 x 285, sw 0.37 -> 1.03 TCUPS, nw 0.40 -> 0.89 with the matrix-lookup traceback kernels; against 5-kaa references the staged references
+            // and per-pair profiles starve the 16-rows-per-lane traceback shapes and the statistics kernel wins).
+            PmxBatch bt = b; bt.perm = nullptr;
+            int variant = 0, Tmax = 0; size_t tbytes = 0;
+            if (pmx_trace16_plan(bt, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes) == 0 && variant >= 10) {
+                double budget = 8e9;
+                { size_t fb = 0, tb = 0; if (hipMemGetInfo(&fb, &tb) == hipSuccess && 0.3 * (double)fb < budget) budget = 0.3 * (double)fb; }
+                const double per_pair = (double)tbytes / (double)n + 1.0;
+                int64_t chunk = (int64_t)(budget / per_pair) / 64 * 64;
+                if (chunk < 64) chunk = 64;
+                if (chunk > n) chunk = n;
+                bt.n = chunk;
+                (void)pmx_trace16_plan(bt, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes);
+                uint32_t *tbuf = nullptr;
+                if (scratch_reserve(tbytes, (void **)&tbuf, SCR_TRACE)) return -1;
+                for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+                    PmxBatch bc = bt;
+                    bc.n = (n - c0 < chunk) ? n - c0 : chunk;
+                    bc.qoff = d_qoff + c0; bc.roff = d_roff + c0;
+                    const int rc = pmx_launch_trace16(variant, bc, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out + c0, tbuf, Tmax,
+                                                      nullptr, nullptr, nullptr, nullptr, st, d_stats_out + c0);
+                    if (rc) { set_err("stats-by-traceback launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+                }
+                g_last_kernel = variant >= 20 ? "pmx_sw16_kernel/packed trace + pmx_walk16_kernel/stats" : "pmx_nwsg16v_kernel/packed trace + pmx_walk16_kernel/stats";
+                return 0;
+            }
+        }
     }
     if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
         const int rc = pmx_launch_stats16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, d_stats_out, st, &g_last_kernel);

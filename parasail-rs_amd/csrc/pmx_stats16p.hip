@@ -52,7 +52,10 @@ __device__ __forceinline__ int p_shift_up(int x)                 // value of lan
 
 struct PCand { int H; int i; int jL; int MS; };                  // true score, row, column | length << 16, matches | similar << 16
 
-template <int G, int R, int WAVES>
+// ML (per-pair queries): no profile planes at all -- the score is a byte read from the transposed matrix in LDS (see
+// pmx_sw16m.hip), the similar increment is "score > 0" read off that byte, the match increment a packed comparison
+// of the query letter codes (kept in registers) with the reference codes of the step.
+template <int G, int R, int WAVES, bool ML>
 __global__ __launch_bounds__(64 * WAVES)
 void pmx_stats16p_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                          const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
@@ -74,8 +77,9 @@ void pmx_stats16p_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__rest
     const int g = lane % G, slotw = lane / G;
     const int pA = wave * NPW + 2 * slotw, pB = pA + 1;
     const int MS1 = msize + 1;
-    const int NPROF = q_shared ? 1 : NP;
-    const int PLANE = NPROF * MS1 * QPS;        // bytes per plane
+    constexpr int MSTR = 32;                    // ML: bytes per row of the transposed matrix
+    const int NPROF = ML ? 0 : (q_shared ? 1 : NP);
+    const int PLANE = ML ? (MS1 * MSTR + 2) / 3 : NPROF * MS1 * QPS;        // bytes per plane (ML: the three "planes" just hold matT)
 
     // LDS carve: [score plane][match plane][similar plane][mat][map][ptab]
     unsigned char *psc = lds, *pim = lds + PLANE, *pis = lds + 2 * PLANE;
@@ -100,6 +104,12 @@ void pmx_stats16p_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__rest
 
     // ---- profile planes: query row i = l * R + k sits at byte l * RS + k (rows >= qlen score 0, no increments)
     const int vcol_b = col_pen ? 0 : open;      // real row x pad symbol (virtual column)
+    if (ML) {       // matT[r][q]: letters score + open; column msize = rows beyond the query (score 0); row msize = the pad symbol
+        for (int i = tid; i < MS1 * MSTR; i += NT) {
+            const int r = i / MSTR, q = i % MSTR;
+            lds[i] = (unsigned char)(r < msize ? (q < msize ? mat[q * msize + r] + open : open) : (q < msize ? vcol_b : open));
+        }
+    }
     for (int p = 0; p < NPROF; ++p) {
         const int qlp = (int)ptab[5 * p + 1];
         const uint8_t *qp = qbuf + ptab[5 * p + 0];
@@ -120,7 +130,7 @@ void pmx_stats16p_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__rest
     __syncthreads();
 
     // ---- per-lane state ------------------------------------------------------------------
-    const int prA = q_shared ? 0 : pA, prB = q_shared ? 0 : pB;
+    const int prA = (q_shared || ML) ? 0 : pA, prB = (q_shared || ML) ? 0 : pB;
     const unsigned char *scA = psc + (size_t)prA * MS1 * QPS + g * RS, *scB = psc + (size_t)prB * MS1 * QPS + g * RS;
     const int qlA = (int)ptab[5 * pA + 1], qlB = (int)ptab[5 * pB + 1];
     const int rlA = (int)ptab[5 * pA + 3], rlB = (int)ptab[5 * pB + 3];
@@ -132,8 +142,25 @@ void pmx_stats16p_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__rest
         rb = (col >= 0 && col < rlB) ? (int)refB[col] : -1;
     };
     auto sym_of = [&](int raw) -> int { return raw < 0 ? msize : (int)map[raw]; };
+    // ML: letter codes of this lane's rows (msize beyond the query): LDS offsets inside a matT row, and packed for the match test
+    int qa[ML ? R : 1], qb_[ML ? R : 1], qc[ML ? R : 1];
+    if (ML) {
+        const uint8_t *qA = qbuf + ptab[5 * pA + 0] + g * R, *qB = qbuf + ptab[5 * pB + 0] + g * R;
+        unsigned char ra[R], rb[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            ra[k] = g * R + k < qlA ? qA[k] : (unsigned char)0;
+            rb[k] = g * R + k < qlB ? qB[k] : (unsigned char)0;
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            qa[k] = g * R + k < qlA ? (int)map[ra[k]] : msize;
+            qb_[k] = g * R + k < qlB ? (int)map[rb[k]] : msize;
+            qc[k] = qa[k] | (qb_[k] << 16);
+        }
+    }
     auto pack2 = [](int a, int b) -> int { return (a & 0xFFFF) | (b << 16); };
-    const int vExt = pack2(ext, ext), vC = pack2(open - ext, open - ext);
+    const int vExt = pack2(ext, ext), vC = pack2(open - ext, open - ext), vOpenP = pack2(open, open);
     const int one2 = 0x00010001;
     const int base = nb + (G - g) * ext - open;      // X-form of a true 0 in column j0 - 1 (j0 = -g is this lane's first column)
 
@@ -175,7 +202,17 @@ void pmx_stats16p_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__rest
                                   corner[h].jL = brow[h].jL = bcol[h].jL = 0; corner[h].MS = brow[h].MS = bcol[h].MS = 0; }
 
     int wsc[2][2][W4], wim[2][2][W4], wis[2][2][W4];     // [buffer][pair half][dword]
+    int wml[2][ML ? R : 1], rc2[2] = {0, 0};             // ML: packed scores of a step, packed reference codes of a step
     auto load_planes = [&](int bsel, int symA, int symB) {
+        if (ML) {
+            rc2[bsel] = symA | (symB << 16);
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int sa = lds[symA * MSTR + qa[k]], sb = lds[symB * MSTR + qb_[k]];
+                wml[bsel][k] = sa | (sb << 16);
+            }
+            return;
+        }
         const int *a0 = reinterpret_cast<const int *>(scA + symA * QPS), *b0 = reinterpret_cast<const int *>(scB + symB * QPS);
         const int *a1 = reinterpret_cast<const int *>(scA + PLANE + symA * QPS), *b1 = reinterpret_cast<const int *>(scB + PLANE + symB * QPS);
         const int *a2 = reinterpret_cast<const int *>(scA + 2 * PLANE + symA * QPS), *b2 = reinterpret_cast<const int *>(scB + 2 * PLANE + symB * QPS);
@@ -203,9 +240,17 @@ void pmx_stats16p_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__rest
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const unsigned selw = 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16);
-            const int s = __builtin_amdgcn_perm(wsc[bsel][1][k / 4], wsc[bsel][0][k / 4], selw);
-            const int im = __builtin_amdgcn_perm(wim[bsel][1][k / 4], wim[bsel][0][k / 4], selw);
-            const int is = __builtin_amdgcn_perm(wis[bsel][1][k / 4], wis[bsel][0][k / 4], selw);
+            int s, im, is;
+            if (ML) {
+                const p_v2u fifteen = {15, 15}, one_ = {1, 1};
+                s = wml[bsel][k];
+                is = P_I32(__builtin_bit_cast(p_v2s, __builtin_bit_cast(p_v2u, P_PK(vOpenP) - P_PK(s)) >> fifteen));            // score + open > open
+                im = P_I32(__builtin_bit_cast(p_v2s, (__builtin_bit_cast(p_v2u, qc[k] ^ rc2[bsel]) - one_) >> fifteen));         // equal letter codes
+            } else {
+                s = __builtin_amdgcn_perm(wsc[bsel][1][k / 4], wsc[bsel][0][k / 4], selw);
+                im = __builtin_amdgcn_perm(wim[bsel][1][k / 4], wim[bsel][0][k / 4], selw);
+                is = __builtin_amdgcn_perm(wis[bsel][1][k / 4], wis[bsel][0][k / 4], selw);
+            }
             T[k] = ((k == 0) ? diag0 : X[k - 1]) + s;
             TM[k] = ((k == 0) ? dM0 : hM[k - 1]) + im;
             TS[k] = ((k == 0) ? dS0 : hS[k - 1]) + is;
@@ -328,23 +373,23 @@ void pmx_stats16p_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__rest
 }
 
 // ------------------------------------------------------------------------ host side ----
-template <int G, int R, int WAVES>
+template <int G, int R, int WAVES, bool ML = false>
 static int launch_statsp(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
                          pmx_record_t *d_out, pmx_stats_t *d_stats, hipStream_t stream)
 {
     constexpr int RS = (R + 3) / 4 * 4, NP = 2 * (64 / G) * WAVES;
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
     const int nprof = b.q_shared ? 1 : NP;
-    const size_t lds = (size_t)3 * nprof * (m.msize + 1) * G * RS + 8 +
+    const size_t lds = (ML ? (size_t)(m.msize + 1) * 32 + 8 : (size_t)3 * nprof * (m.msize + 1) * G * RS) + 8 +
                        (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
     if (lds > 160 * 1024) return 1;
-    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_stats16p_kernel<G, R, WAVES>)); if (rc) return rc; }
+    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_stats16p_kernel<G, R, WAVES, ML>)); if (rc) return rc; }
     const bool sg = mode == PMX_MODE_SG;
     const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL((pmx_stats16p_kernel<G, R, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream,
+    hipLaunchKernelGGL((pmx_stats16p_kernel<G, R, WAVES, ML>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                        m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb,
                        b.perm, d_out, d_stats);
@@ -361,7 +406,9 @@ int pmx_launch_stats16p(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     // Where it pays (measured): one shared query profile per workgroup (the profile arm, config 3) and results that
     // are captured once per pair (no free end: nw, sg_qb, sg_db, sg_qb_db).  Per-pair profiles cost too much LDS
     // in three planes, and per-step last-row / last-column captures are cheaper in the unpacked kernel.
-    if (!b.q_shared && !getenv("PMX_STATS16P_ALWAYS")) return 1;
+    // Per-pair queries: only over large alphabets, with the matrix-lookup variant (no profile planes).
+    const bool ml = !b.q_shared && m.msize > 8 && m.msize < 32 && !getenv("PMX_STATS16P_NO_MATRIX_LOOKUP");
+    if (!b.q_shared && !ml && !getenv("PMX_STATS16P_ALWAYS")) return 1;
     if (mode == PMX_MODE_SG && (sg_flags & (PMX_SG_QE | PMX_SG_DE)) && !getenv("PMX_STATS16P_ALWAYS")) return 1;
     if (ext < 1 || b.max_qlen + b.max_rlen + 2 > 32767) return 1;          // statistics live in int16 halves
     const int nb = pmx_nwsgv_bias(b, m, open, ext);                         // same window proof as the score kernel
@@ -370,9 +417,10 @@ int pmx_launch_stats16p(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     const int W = b.q_shared ? 4 : 1;      // a shared query profile is built once per 4-wave workgroup
 #define TRYP(GG, RR, NAME)                                                      \
     if (q <= (GG) * (RR)) {                                                     \
-        int rc = W == 4 ? launch_statsp<GG, RR, 4>(b, m, mode, sg_flags, open, ext, nb, d_out, d_stats, stream)  \
+        int rc = ml ? launch_statsp<GG, RR, 1, true>(b, m, mode, sg_flags, open, ext, nb, d_out, d_stats, stream)  \
+               : W == 4 ? launch_statsp<GG, RR, 4>(b, m, mode, sg_flags, open, ext, nb, d_out, d_stats, stream)  \
                         : launch_statsp<GG, RR, 1>(b, m, mode, sg_flags, open, ext, nb, d_out, d_stats, stream); \
-        if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; }       \
+        if (rc <= 0) { if (kernel_name) *kernel_name = ml ? NAME "/matrix lookup" : NAME; return rc; }       \
     }
     TRYP(16, 10, "pmx_stats16p_kernel<16,10>")
     TRYP(32, 10, "pmx_stats16p_kernel<32,10>")

@@ -884,14 +884,30 @@ def test_stats16p_packed_kernel_everywhere(pkg, orc, monkeypatch, gaps):
 
 
 def test_stats_by_traceback_protein_short_references(pkg, orc):
-    """large alphabets, per-pair queries, short references, a full batch: statistics counted along the packed traceback"""
+    """large alphabets, per-pair queries, short references, a full batch: the matrix-lookup statistics kernel without
+    free ends, statistics counted along the packed traceback otherwise"""
     rng = np.random.default_rng(5400)
     pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
     qs = random_seqs(rng, 2100, 40, 200, AA)
     rs = [mutate(rng, q, 0.3, 0.06, AA) if i % 3 else random_seqs(rng, 1, 10, 260, AA)[0] for i, q in enumerate(qs)]
-    for mode, sg in ((2, None), (0, None), (1, None), (1, orc.S1_BEG | orc.S2_END)):
+    for mode, sg, route in ((2, None, "trace"), (0, None, "lookup"), (1, None, "trace"), (1, orc.S1_BEG | orc.S2_END, "trace"),
+                            (1, orc.S1_BEG | orc.S2_BEG, "lookup")):
         _stats_case(pkg, orc, mode, sg, qs, rs, 11, 1, pm, om)
-        assert pkg.lib.pmx_last_kernel().decode().endswith("pmx_walk16_kernel/stats")
+        k = pkg.lib.pmx_last_kernel().decode()
+        # no free end: the packed statistics kernel with matrix lookup; otherwise counts along the packed traceback
+        assert k.endswith("pmx_walk16_kernel/stats") if route == "trace" else k.startswith("pmx_stats16p_kernel") and k.endswith("matrix lookup")
+
+
+def test_stats16p_matrix_lookup_long_references(pkg, orc):
+    """config 3's one-off form: per-pair protein queries against long references, global + statistics"""
+    rng = np.random.default_rng(5500)
+    pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    for qlo, qhi, n in ((40, 160, 24), (250, 320, 16), (500, 640, 8)):
+        qs = random_seqs(rng, n, qlo, qhi, AA)
+        rs = [random_seqs(rng, 1, 300, 1500, AA)[0] + mutate(rng, q, 0.3, 0.05, AA) + random_seqs(rng, 1, 300, 1500, AA)[0] for q in qs]
+        for mode, sg in ((0, None), (1, orc.S2_BEG), (1, orc.S1_BEG | orc.S2_BEG)):
+            _stats_case(pkg, orc, mode, sg, qs, rs, 11, 1, pm, om)
+            assert pkg.lib.pmx_last_kernel().decode().endswith("matrix lookup")
 
 
 def test_stats16_shared_query_blosum62(pkg, orc):
