@@ -965,7 +965,9 @@ extern "C" const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen,
 
 // grow-only per-(thread,device) scratch for the general kernel's band boundary rows
 struct Scratch { void *p = nullptr; size_t cap = 0; int dev = -1; };
-enum { SCR_BOUND = 0, SCR_TRACE = 1, SCR_OPS = 2, SCR_SORT = 3, SCR_RETRY = 4, SCR_SLOTS = 5 };
+enum { SCR_BOUND = 0, SCR_TRACE = 1, SCR_OPS = 2, SCR_SORT = 3, SCR_RETRY = 4,
+       SCR_HQ = 5, SCR_HR = 6, SCR_HQO = 7, SCR_HRO = 8, SCR_HREC = 9, SCR_HST = 10,      // staging of the host-buffer batch entry
+       SCR_SLOTS = 11 };
 static thread_local Scratch g_scratch_pool[SCR_SLOTS];
 static int scratch_reserve(size_t bytes, void **out, int slot = SCR_BOUND)
 {
@@ -1174,10 +1176,14 @@ extern "C" int pmx_align_batch(const pmx_config_t *cfg, int64_t n,
     cfg = &cfg_s;
     const size_t qbytes = (size_t)(qoff[n] - qoff[0]), rbytes = (size_t)(roff[n] - roff[0]);
     if (qoff[0] != 0 || roff[0] != 0) { set_err("offset arrays must start at 0"); return -1; }
-    DevBuf<uint8_t> dq, dr; DevBuf<int64_t> dqo, dro; DevBuf<pmx_record_t> drec; DevBuf<pmx_stats_t> dst;
-    dq.alloc(qbytes); dr.alloc(rbytes); dqo.alloc(n + 1); dro.alloc(n + 1); drec.alloc(n);
+    // device staging is kept per host thread between calls (hipMalloc / hipFree of hundreds of MB cost milliseconds)
+    struct { uint8_t *p; } dq, dr; struct { int64_t *p; } dqo, dro; struct { pmx_record_t *p; } drec; struct { pmx_stats_t *p; } dst = {nullptr};
     const bool stats = cfg->want & PMX_WANT_STATS;
-    if (stats) { if (!stats_out) { set_err("stats requested without a stats buffer"); return -1; } dst.alloc(n); }
+    if (stats && !stats_out) { set_err("stats requested without a stats buffer"); return -1; }
+    if (scratch_reserve(qbytes, (void **)&dq.p, SCR_HQ) || scratch_reserve(rbytes, (void **)&dr.p, SCR_HR) ||
+        scratch_reserve(sizeof(int64_t) * (n + 1), (void **)&dqo.p, SCR_HQO) || scratch_reserve(sizeof(int64_t) * (n + 1), (void **)&dro.p, SCR_HRO) ||
+        scratch_reserve(sizeof(pmx_record_t) * n, (void **)&drec.p, SCR_HREC) ||
+        (stats && scratch_reserve(sizeof(pmx_stats_t) * n, (void **)&dst.p, SCR_HST))) return -1;
     HIP_OR_RET(hipMemcpy(dqo.p, qoff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     if (n >= 262144 && !(cfg->want & PMX_WANT_SORTED)) {
