@@ -32,7 +32,7 @@ class _Outputs(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("pmx_oracle.c", "pmx_striped_cpu.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("pmx_oracle.c", "pmx_oracle_batch.c", "pmx_striped_cpu.c", "Makefile")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -53,6 +53,9 @@ def lib():
         _lib.orc_walk.restype = C.c_int
         _lib.orc_align_batch.restype = C.c_int
         _lib.pmx_cpu_sw_striped16_batch.restype = C.c_int
+        _lib.orc_align_stats_sample.restype = C.c_int
+        _lib.orc_cigar_sample.restype = C.c_int
+        _lib.orc_rescore_cigars.restype = C.c_long
     return _lib
 
 
@@ -219,3 +222,57 @@ def cpu_sw_striped16_batch(qbuf, qoff, rbuf, roff, open_, ext, matrix, threads=0
                                             int(open_), int(ext), _ptr(matrix.scores), matrix.size,
                                             _ptr(matrix.mapper), _ptr(out), int(threads))
     return out, used
+
+
+def align_stats_sample(mode, index, qbuf, qoff, rbuf, roff, open_, ext, matrix, sg_flags=SG_ALL, bits=0, shared_query=None):
+    """Pairs `index` of a packed batch with statistics -> int32 [m, 7]: score, end_query, end_ref, matches, similar,
+    length, saturated.  shared_query: bytes of the one query every pair uses (profile arm)."""
+    index = np.ascontiguousarray(index, dtype=np.int64)
+    out = np.zeros((len(index), 7), dtype=np.int32)
+    roff = np.ascontiguousarray(roff, dtype=np.int64)
+    if shared_query is not None:
+        qb = np.frombuffer(bytes(shared_query), dtype=np.uint8)
+        rc = lib().orc_align_stats_sample(mode, sg_flags, C.c_long(len(index)), _ptr(index), _ptr(qb), None, len(qb),
+                                          _ptr(rbuf), _ptr(roff), int(open_), int(ext), _ptr(matrix.scores), matrix.size,
+                                          _ptr(matrix.mapper), int(bits), _ptr(out))
+    else:
+        qoff = np.ascontiguousarray(qoff, dtype=np.int64)
+        rc = lib().orc_align_stats_sample(mode, sg_flags, C.c_long(len(index)), _ptr(index), _ptr(qbuf), _ptr(qoff), 0,
+                                          _ptr(rbuf), _ptr(roff), int(open_), int(ext), _ptr(matrix.scores), matrix.size,
+                                          _ptr(matrix.mapper), int(bits), _ptr(out))
+    if rc:
+        raise RuntimeError("orc_align_stats_sample: some pair failed")
+    return out
+
+
+def cigar_sample(mode, index, qbuf, qoff, rbuf, roff, open_, ext, matrix, sg_flags=SG_ALL):
+    """Pairs `index` of a packed batch: (list of CIGAR text, int32 [m, 5]: score, end_query, end_ref, beg_query, beg_ref)."""
+    index = np.ascontiguousarray(index, dtype=np.int64)
+    qoff = np.ascontiguousarray(qoff, dtype=np.int64)
+    roff = np.ascontiguousarray(roff, dtype=np.int64)
+    m = len(index)
+    stride = int(12 * ((qoff[1:] - qoff[:-1])[index] + (roff[1:] - roff[:-1])[index]).max() + 16) if m else 16
+    text = np.zeros((m, stride), dtype=np.uint8)
+    rec = np.zeros((m, 5), dtype=np.int32)
+    rc = lib().orc_cigar_sample(mode, sg_flags, C.c_long(m), _ptr(index), _ptr(qbuf), _ptr(qoff), _ptr(rbuf), _ptr(roff),
+                                int(open_), int(ext), _ptr(matrix.scores), matrix.size, _ptr(matrix.mapper),
+                                _ptr(text), stride, _ptr(rec))
+    if rc:
+        raise RuntimeError("orc_cigar_sample: some pair failed")
+    return [bytes(row).split(b"\0", 1)[0].decode() for row in text], rec
+
+
+def rescore_cigars(text, toff, qbuf, qoff, rbuf, roff, open_, ext, matrix, beg=None, free_mask=0):
+    """Independent re-scoring of CIGAR text (uint8 buffer + int64 offsets) -> (int32 [n, 4]: score, query consumed,
+    reference consumed, mislabelled =/X columns; number of malformed texts)."""
+    n = len(toff) - 1
+    out = np.zeros((n, 4), dtype=np.int32)
+    toff = np.ascontiguousarray(toff, dtype=np.int64)
+    qoff = np.ascontiguousarray(qoff, dtype=np.int64)
+    roff = np.ascontiguousarray(roff, dtype=np.int64)
+    if beg is not None:
+        beg = np.ascontiguousarray(beg, dtype=np.int32)
+    bad = lib().orc_rescore_cigars(C.c_long(n), _ptr(text), _ptr(toff), _ptr(qbuf), _ptr(qoff), _ptr(rbuf), _ptr(roff),
+                                   _ptr(beg), int(open_), int(ext), int(free_mask), _ptr(matrix.scores), matrix.size,
+                                   _ptr(matrix.mapper), _ptr(out))
+    return out, int(bad)

@@ -749,6 +749,12 @@ class Aligner:
     def align_batch_cigar(self, queries, references):
         qbuf, qoff = pack(queries)
         rbuf, roff = pack(references)
+        out, text, coff = self.align_batch_cigar_packed(qbuf, qoff, rbuf, roff)
+        raw = text.tobytes()
+        return out, [raw[coff[k]:coff[k + 1]].decode() for k in range(len(roff) - 1)]
+
+    def align_batch_cigar_packed(self, qbuf, qoff, rbuf, roff):
+        """Packed in, packed out: (records, CIGAR text as one uint8 array, int64 offsets[n+1])."""
         n = len(roff) - 1
         cfg = self._config()
         cfg.want &= ~WANT_STATS
@@ -759,9 +765,9 @@ class Aligner:
                                        roff.ctypes.data, out.ctypes.data, C.byref(cbuf), coff.ctypes.data)
         if rc:
             raise BatchError(lib.pmx_last_error().decode())
-        text = C.string_at(cbuf, int(coff[n]))
+        text = np.frombuffer(C.string_at(cbuf, int(coff[n])), dtype=np.uint8)
         lib.pmx_free(cbuf)
-        return out, [text[coff[k]:coff[k + 1]].decode() for k in range(n)]
+        return out, text, coff
 
 
 def pack(seqs):
