@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's headline metric on MI355X.
+"""bench.py -- BASELINE.json's configs on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--config 2|3|4|5] [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (`sw_striped_16`, score + end positions) over one batch of
-synthetic pairs that is already resident in HBM: BASELINE config 2, 1 000 000 pairs of 150 bp x
-150 bp i.i.d. DNA, Matrix::create("ACGT", 2, -3), gap open 5 / extend 2.
-Every rank holds its own 1M-pair batch (weak scaling, no data-path collective); for N > 1 the
-records of each step are gathered to rank 0 over RCCL, overlapped with the next step's kernel.
-Rank 0 prints ONE JSON line.
+Default: config 2, the headline -- a "step" is one pass of the hot path (`sw_striped_16`, score + end
+positions) over one batch of synthetic pairs already resident in HBM: 1 000 000 pairs of 150 bp x 150 bp
+i.i.d. DNA, Matrix::create("ACGT", 2, -3), gap open 5 / extend 2.
+`--config 3|4|5` measures the other BASELINE configs the same way (workloads.py), each at ONE GPU's share of
+the config (cfg 3: all 100k references -- the config is quoted on one GPU; cfg 4 / 5: 1.25M of the 10M).
+Weak scaling (default): every rank holds its own batch of that size.  `--scaling strong`: the N = 1 batch is
+split across the ranks by the shard planner (uniform for equal lengths, cumulative cells for mixed lengths).
+No data-path collective; for N > 1 the records of each step are gathered to rank 0 over RCCL, overlapped
+with the next step's kernel.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -22,29 +26,41 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import workloads as wl  # noqa: E402
 
-N_PAIRS = 1_000_000
-LEN = 150
-SEED = 20260001
-MATCH, MISMATCH, OPEN, EXT = 2, -3, 5, 2
-ALGO_BYTES_PER_PAIR = LEN + LEN + 12          # 312 B / pair
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# VALU ceiling for the hot kernel (DESIGN.md "Roofline").  Measured issue rates on this chip
-# (profiles/r01/valu_rate_microbench.txt): a VOP3/VOP3P wave64 instruction (v_pk_maximum3_f16,
-# v_perm_b32, v_bfi_b32) takes 4 cycles of its SIMD, a 32-bit-encoded VOP2 (v_add_u32, v_sub_u32)
-# 2 cycles.  Per 2 cells x 64 lanes the skewed max3+vop2 variant issues 5.5 VOP3 + 3 VOP2 = 28 cycles.
-SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
-CYCLES_PER_128_CELLS = 5.5 * 4 + 3 * 2
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9           # 256 CUs x 4 SIMDs x 2.4 GHz
+
+# Back-compat names (tests import them)
+N_PAIRS = wl.CFG2["n"]
+LEN = wl.CFG2["len"]
 
 
-def make_cfg2_inputs(n=N_PAIRS, seed=SEED):
-    """numpy.random.default_rng(seed): queries first, then references, 0..3 -> ACGT."""
-    rng = np.random.default_rng(seed)
-    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
-    q = lut[rng.integers(0, 4, size=(n, LEN), dtype=np.uint8)].reshape(-1)
-    r = lut[rng.integers(0, 4, size=(n, LEN), dtype=np.uint8)].reshape(-1)
-    off = np.arange(n + 1, dtype=np.int64) * LEN
-    return q, off, r, off.copy()
+def make_cfg2_inputs(n=N_PAIRS, seed=wl.CFG2["seed"]):
+    return wl.make_cfg2(n, rank=seed - wl.CFG2["seed"])
+
+
+# VALU ceilings (DESIGN.md "Roofline").  Measured issue rates on this chip (profiles/r01/valu_rate_microbench.txt):
+# a VOP3 / VOP3P wave64 instruction (v_pk_maximum3_f16, v_perm_b32, v_bfi_b32, packed adds) takes 4 cycles of its
+# SIMD, a 32-bit-encoded VOP2 (v_add_u32, v_sub_u32) 2 cycles.  Counted inner-loop instructions per 2 cells x 64
+# lanes (= 128 cells), by kernel family: (VOP3, VOP2, what).
+VALU_MODEL = {
+    "pmx_sw16_kernel": (5.5, 3.0, "sw16 skewed max3+vop2 variant: 5.5 VOP3/VOP3P + 3 VOP2 per 128 cells"),
+    "pmx_sw16q_kernel": (5.5, 3.0, "sw16q (shared profile): 5.5 VOP3/VOP3P + 3 VOP2 per 128 cells"),
+    "pmx_stats16p_kernel": (30.0, 4.0, "stats16p: score arithmetic 7 + nine statistic planes moved by v_bfi_b32 under sign masks"),
+    "pmx_stats16c_kernel": (17.0, 4.0, "stats16c: score arithmetic 7 + one combined statistics word per H/E/F moved by v_cndmask"),
+    "pmx_nwsg16v_kernel/packed trace": (12.75, 2.0, "nwsg16v + traceback: 7 score + 4 packed differences + 3.75 bit merges per 128 cells"),
+    "pmx_nwsg16v_kernel": (4.0, 3.0, "nwsg16v: 4 VOP3/VOP3P + 3 VOP2 per 128 cells"),
+}
+
+
+def valu_ceiling(kernel):
+    for key in sorted(VALU_MODEL, key=len, reverse=True):
+        if key.split("/")[0] in kernel and all(p in kernel for p in key.split("/")[1:]):
+            v3, v2, what = VALU_MODEL[key]
+            cyc = v3 * 4 + v2 * 2
+            return SIMD_CYCLES_PER_S / cyc * 128.0 / 1e9, "%s = %.1f SIMD cycles; 1024 SIMDs x 2.4 GHz" % (what, cyc)
+    return None, None
 
 
 def usable_cores():
@@ -70,91 +86,355 @@ def usable_cores():
     return cores
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/<round>/*pmc_summary.json: FETCH_SIZE and WRITE_SIZE in KiB, separate passes).
-    gfx950 correction from MI355X_MICROARCH.md: FETCH_SIZE counts half of the fetched bytes."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")))
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def pmc_summary(config, kernel):
+    """Counters of the dominant kernel from the committed PMC passes (profiles/r*/cfg<N>_pmc_summary.json, made by
+    profiles/run_profile.sh + summarize_pmc.py: separate --pmc passes).  Used only when the profiled kernel is the
+    one that just ran; the source file is named in the line.  gfx950 correction (MI355X_MICROARCH.md):
+    FETCH_SIZE counts half of the fetched bytes; both counters are in KiB."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "cfg%d_pmc_summary.json" % config)))
     if not files:
         return None
     try:
         d = json.load(open(files[-1]))
-        return int((2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024)
-    except Exception:
-        return None
-
-
-def cpu_reference_baseline(qbuf, rbuf, cores):
-    """If the box has the reference's real library (a system libparasail), time `parasail_sw_striped_16`
-    on all usable cores, one thread per core over its slice of pairs (the pattern of the reference's
-    tests/test_parasail.rs:702-717).  Returns None when it is absent (it is, in the build image)."""
-    try:
-        from oracle import parasail_probe
-        lib = parasail_probe.load()
-        if lib is None:
+        if d.get("kernel", "") and d["kernel"].split("<")[0] not in kernel:
             return None
-        from concurrent.futures import ThreadPoolExecutor
-        sample = 65536
-        qs = [qbuf[k * LEN:(k + 1) * LEN].tobytes() for k in range(sample)]
-        rs = [rbuf[k * LEN:(k + 1) * LEN].tobytes() for k in range(sample)]
-        per = (sample + cores - 1) // cores
-        def work(c):
-            return parasail_probe.align_batch(lib, b"sw_striped_16", qs[c * per:(c + 1) * per], rs[c * per:(c + 1) * per],
-                                              OPEN, EXT, b"ACGT", MATCH, MISMATCH)
-        with ThreadPoolExecutor(cores) as ex:
-            list(ex.map(work, range(cores)))                # warm-up
-            t0 = time.perf_counter()
-            parts = list(ex.map(work, range(cores)))
-            t = time.perf_counter() - t0
-        out = np.array([x for p in parts for x in p], dtype=np.int32)
-        return {"value": round(sample * LEN * LEN / t / 1e9, 3), "unit": "GCUPS", "cores": int(cores), "kind": "reference",
-                "sample": "%d of the same 150x150 pairs, system libparasail parasail_sw_striped_16 via ctypes, one thread per core, "
-                          "%.2f s wall" % (sample, t)}, out
+        out = {"source": os.path.relpath(files[-1], ROOT), "profiled_kernel": d.get("kernel")}
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            out["traffic"] = int((2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+        if "SQ_LDS_BANK_CONFLICT" in d and "SQ_LDS_IDX_ACTIVE" in d:
+            out["lds_bank_conflict"] = {"conflict_cycles": int(d["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"]),
+                                        "lds_active_cycles": int(d["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"]),
+                                        "frac": round(d["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] /
+                                                      max(1.0, d["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"]), 4)}
+        return out
     except Exception:
         return None
 
 
-def cpu_baseline(qbuf, qoff, rbuf, roff):
-    """The CPU port of the reference's kernel class (Farrar striped int16, AVX2 + OpenMP), all host
-    cores, on a bounded sample of the same workload (or the real library, if the box has one)."""
-    ref = cpu_reference_baseline(qbuf, rbuf, usable_cores())
-    if ref is not None:
-        return ref
-    from oracle import oracle as orc
-    m = orc.Matrix.create("ACGT", MATCH, MISMATCH)
-    cores = usable_cores()
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+# ------------------------------------------------------------------------------------------ workloads ----
+class Workload:
+    """One BASELINE config: inputs resident in HBM, one `step()` = one pass of the hot path over the batch."""
+    config = 0
+    dtype = "int16"
+    default_steps, default_warmup = 20, 2
 
-    def run(npairs):
+    def __init__(self, pkg, torch, dev, rank, world, scaling, n_override):
+        self.pkg, self.torch, self.dev, self.rank, self.world, self.scaling = pkg, torch, dev, rank, world, scaling
+        self.n_override = n_override
+
+    def shard(self, qlens, rlens):
+        """Strong scaling: this rank's [lo, hi) of the N = 1 batch and every rank's count."""
+        from importlib import import_module
+        sh = import_module("parasail_rs_amd.sharding")
+        n = len(rlens)
+        if np.all(rlens == rlens[0]) and np.all(qlens == qlens[0]):
+            b = sh.shard_bounds_uniform(n, self.world)
+        else:
+            b = sh.shard_bounds_by_cells(qlens, rlens, self.world)
+        return b[self.rank], b[self.rank + 1], [b[k + 1] - b[k] for k in range(self.world)]
+
+    def to_dev(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+
+    def records(self, k):
+        return self.d_out[k % 2]
+
+
+class Cfg2(Workload):
+    config = 2
+    metric = "GCUPS (cell updates/s) local-affine SW, 1M 150x150 pairs, 1/2/4/8 GPUs"
+    default_steps, default_warmup = 100, 5
+
+    def setup(self):
+        c = wl.CFG2
+        n = self.n_override or c["n"]
+        strong = self.scaling == "strong" and self.world > 1
+        qbuf, qoff, rbuf, roff = wl.make_cfg2(n, rank=0 if strong else self.rank)
+        self.counts = [n] * self.world
+        if strong:
+            lo, hi, self.counts = self.shard(np.full(n, c["len"]), np.full(n, c["len"]))
+            qbuf, rbuf = qbuf[qoff[lo]:qoff[hi]], rbuf[roff[lo]:roff[hi]]
+            qoff, roff = qoff[lo:hi + 1] - qoff[lo], roff[lo:hi + 1] - roff[lo]
+            n = hi - lo
+        self.n, self.h = n, (qbuf, qoff, rbuf, roff)
+        self.d = [self.to_dev(x) for x in self.h]
+        self.d_out = [self.torch.zeros((n, 4), dtype=self.torch.int32, device=self.dev) for _ in range(2)]
+        self.matrix = self.pkg.Matrix.create(c["matrix"][0].encode(), c["matrix"][1], c["matrix"][2])
+        self.cfg = self.pkg.pmx_config_t(self.pkg.MODE_SW, 0, c["open"], c["ext"], 16, 0, self.matrix.inner)
+        self.cells = n * c["len"] * c["len"]
+        self.algo_bytes = (2 * c["len"] + 12) * n          # SURVEY.md 8(d): 312 B / pair
+        self.algo_note = "150 + 150 sequence bytes + 12 record bytes per pair (SURVEY.md 8d)"
+        self.workload = "cfg2: %d pairs/GPU x (150 bp x 150 bp) i.i.d. DNA, %s (score + end positions), " \
+                        "Matrix::create(ACGT,2,-3), gaps 5/2" % (n, c["name"])
+
+    def step(self, k, stream):
+        d = self.d
+        self.pkg.align_batch_device(self.cfg, self.n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                    wl.CFG2["len"], wl.CFG2["len"], self.d_out[k % 2].data_ptr(), None, stream.cuda_stream)
+
+    def pcie_inclusive(self):
+        c = wl.CFG2
+        al = self.pkg.Aligner.new().local().matrix(self.matrix).gap_open(c["open"]).gap_extend(c["ext"]).solution_width(16).build()
+        al.align_batch_packed(*self.h)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); al.align_batch_packed(*self.h); ts.append(time.perf_counter() - t0)
+        return {"value": round(self.cells / min(ts) / 1e9, 1), "unit": "GCUPS", "ms": round(min(ts) * 1e3, 3),
+                "entry": "pmx_align_batch (pageable host buffers in, host records out)"}
+
+    def cpu_baseline(self, last_out):
+        from oracle import oracle as orc
+        c = wl.CFG2
+        m = orc.Matrix.create(c["matrix"][0], c["matrix"][1], c["matrix"][2])
+        cores = usable_cores()
+        qbuf, qoff, rbuf, roff = self.h
+        L = c["len"]
+
+        def run(npairs, lanes):
+            t0 = time.perf_counter()
+            out, used = orc.cpu_sw_striped16_batch(qbuf[: npairs * L], qoff[: npairs + 1], rbuf[: npairs * L],
+                                                   roff[: npairs + 1], c["open"], c["ext"], m, threads=cores, lanes=lanes)
+            return time.perf_counter() - t0, used, out
+        widths = (16, 32) if orc.cpu_striped_lanes() == 32 else (16,)
+        run(2048, 16)                                        # warm-up (thread pool, page-in)
+        rate = {w: 16384 / max(run(16384, w)[0], 1e-6) for w in widths}
+        lanes = max(rate, key=rate.get)                      # the faster vector width on this CPU
+        sample = int(min(self.n, max(16384, rate[lanes] * 2.0)))     # ~2 s wall
+        t, used, out = run(sample, lanes)
+        v = sample * L * L / t / 1e9
+        agrees = bool((last_out[:sample, :3] == out).all())
+        return {"value": round(v, 3), "unit": "GCUPS", "cores": int(used), "per_core": round(v / used, 3), "kind": "port",
+                "sample": "%d of the same 150x150 pairs, restated CPU baseline (not parasail): striped int16 %s + OpenMP, "
+                          "per-pair profiles (oracle/pmx_striped_cpu.c; the faster of the CPU's vector widths), %s, %.2f s wall"
+                          % (sample, "AVX-512BW x32" if lanes == 32 else "AVX2 x16", cpu_model(), t),
+                "agrees_with_gpu": agrees}
+
+
+class Cfg3(Workload):
+    config = 3
+    metric = "GCUPS (cell updates/s) global NW + statistics, reused 300-aa profile vs 100k x ~4.75 kaa, BLOSUM62 11/1"
+    default_steps, default_warmup = 10, 2
+
+    def setup(self):
+        c = wl.CFG3
+        n = self.n_override or c["n"]
+        strong = self.scaling == "strong" and self.world > 1
+        q, rbuf, roff = wl.make_cfg3(n, rank=0 if strong else self.rank)
+        self.counts = [n] * self.world
+        if strong:
+            rl = roff[1:] - roff[:-1]
+            lo, hi, self.counts = self.shard(np.full(n, c["qlen"]), rl)
+            rbuf, roff = rbuf[roff[lo]:roff[hi]], roff[lo:hi + 1] - roff[lo]
+            n = hi - lo
+        self.n, self.q, self.h = n, q, (rbuf, roff)
+        self.d = [self.to_dev(x) for x in self.h]
+        self.d_out = [self.torch.zeros((n, 4), dtype=self.torch.int32, device=self.dev) for _ in range(2)]
+        self.d_st = [self.torch.zeros((n, 3), dtype=self.torch.int32, device=self.dev) for _ in range(2)]
+        self.matrix = self.pkg.Matrix.from_name(c["matrix"])
+        self.profile = self.pkg.Profile.new(q, True, self.matrix)
+        self.cfg = self.pkg.pmx_config_t(self.pkg.MODE_NW, 0, c["open"], c["ext"], 16, self.pkg.WANT_STATS, self.matrix.inner)
+        self.max_rlen = int((roff[1:] - roff[:-1]).max())
+        self.cells = int(c["qlen"] * roff[-1])
+        self.algo_bytes = int(roff[-1]) + 24 * n          # SURVEY.md 8(d): rlen + 24 B / pair
+        self.algo_note = "reference bytes + 12 record + 12 statistics bytes per pair (SURVEY.md 8d); the profile is read once per workgroup"
+        self.workload = "cfg3: one 300-aa query (reused stats profile) x %d references/GPU of 4.5-5 kaa, %s " \
+                        "(score, ends, matches, similar, length), BLOSUM62, gaps 11/1" % (n, c["name"])
+
+    def step(self, k, stream):
+        self.pkg.align_profile_batch_device(self.cfg, self.profile, self.n, self.d[0].data_ptr(), self.d[1].data_ptr(),
+                                            self.max_rlen, self.d_out[k % 2].data_ptr(), self.d_st[k % 2].data_ptr(),
+                                            stream.cuda_stream)
+
+    def cpu_baseline(self, last_out):
+        from oracle import oracle as orc
+        c = wl.CFG3
+        om = orc.Matrix.from_file(os.path.join(ROOT, "tests", "golden", "blosum62.txt"))
+        cores = usable_cores()
+        os.environ["OMP_NUM_THREADS"] = str(cores)
+        rbuf, roff = self.h
+        m = min(self.n, 8 * cores)
+        idx = np.arange(m)
+        orc.align_stats_sample(orc.NW, idx[:cores], None, None, rbuf, roff, c["open"], c["ext"], om, bits=16, shared_query=self.q)
         t0 = time.perf_counter()
-        out, used = orc.cpu_sw_striped16_batch(qbuf[: npairs * LEN], qoff[: npairs + 1], rbuf[: npairs * LEN],
-                                               roff[: npairs + 1], OPEN, EXT, m, threads=cores)
-        return time.perf_counter() - t0, used, out
-    run(2048)                                           # warm-up (thread pool, page-in)
-    t, used, _ = run(16384)
-    rate = 16384 / max(t, 1e-6)
-    sample = int(min(N_PAIRS, max(16384, rate * 2.0)))  # ~2 s wall
-    t, used, out = run(sample)
-    cpu = "unknown CPU"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {"value": round(sample * LEN * LEN / t / 1e9, 3), "unit": "GCUPS", "cores": int(used), "kind": "port",
-            "sample": "%d of the same 150x150 pairs, restated CPU baseline (not parasail): striped int16 AVX2 + OpenMP "
-                      "(oracle/pmx_striped_cpu.c, gcc -O2 -march=x86-64-v3 -fopenmp), %s, %.2f s wall" % (sample, cpu, t)}, out
+        want = orc.align_stats_sample(orc.NW, idx, None, None, rbuf, roff, c["open"], c["ext"], om, bits=16, shared_query=self.q)
+        t = time.perf_counter() - t0
+        v = c["qlen"] * int(roff[m]) / t / 1e9
+        st = self.d_st[self.last_k % 2][:m].cpu().numpy()
+        agrees = bool((last_out[:m, :3] == want[:, :3]).all() and (st == want[:, 3:6]).all())
+        return {"value": round(v, 3), "unit": "GCUPS", "cores": int(cores), "per_core": round(v / cores, 3), "kind": "port",
+                "sample": "the first %d references of the same batch, restated CPU baseline (not parasail): SCALAR Gotoh DP with the "
+                          "coupled statistics tables (oracle/pmx_oracle.c, gcc -O2) under OpenMP -- no vectorised CPU port of the "
+                          "stats mode exists in this repo, so this understates what parasail's striped stats kernel would do; %s, "
+                          "%.2f s wall" % (m, cpu_model(), t),
+                "agrees_with_gpu": agrees}
+
+
+class Cfg4(Workload):
+    config = 4
+    metric = "GCUPS (cell updates/s) semi-global affine with traceback + CIGAR text, 250x250 related DNA pairs"
+    default_steps, default_warmup = 20, 2
+    TEXT_CAP_PER_PAIR = 320           # bytes of CIGAR text reserved per pair (the entry reports the bytes it needed)
+
+    def setup(self):
+        c = wl.CFG4
+        n = self.n_override or c["n"] // 8
+        strong = self.scaling == "strong" and self.world > 1
+        qbuf, qoff, rbuf, roff = wl.make_cfg4(n, rank=0 if strong else self.rank)
+        self.counts = [n] * self.world
+        if strong:
+            lo, hi, self.counts = self.shard(np.full(n, c["len"]), np.full(n, c["len"]))
+            qbuf, rbuf = qbuf[qoff[lo]:qoff[hi]], rbuf[roff[lo]:roff[hi]]
+            qoff, roff = qoff[lo:hi + 1] - qoff[lo], roff[lo:hi + 1] - roff[lo]
+            n = hi - lo
+        self.n, self.h = n, (qbuf, qoff, rbuf, roff)
+        self.d = [self.to_dev(x) for x in self.h]
+        t = self.torch
+        self.d_out = [t.zeros((n, 4), dtype=t.int32, device=self.dev) for _ in range(2)]
+        self.cap = self.TEXT_CAP_PER_PAIR * n
+        self.d_text = [t.zeros(self.cap, dtype=t.uint8, device=self.dev) for _ in range(2)]
+        self.d_toff = [t.zeros(n + 1, dtype=t.int64, device=self.dev) for _ in range(2)]
+        self.matrix = self.pkg.Matrix.create(c["matrix"][0].encode(), c["matrix"][1], c["matrix"][2])
+        self.cfg = self.pkg.pmx_config_t(self.pkg.MODE_SG, self.pkg.SG_ALL, c["open"], c["ext"], 16, self.pkg.WANT_CIGAR, self.matrix.inner)
+        self.cells = n * c["len"] * c["len"]
+        self.algo_bytes = None                         # 512 B/pair + the CIGAR text actually produced: known after the first step
+        self.algo_note = "250 + 250 sequence bytes + 12 record bytes + the CIGAR text produced per pair (SURVEY.md 8d); the 4-bit " \
+                         "traceback cells are scratch, not algorithmic bytes"
+        self.workload = "cfg4: %d pairs/GPU x (250 bp x 250 bp) related DNA (10%% subs, 2%% indels), %s + CIGAR text on the " \
+                        "device, Matrix::create(ACGT,2,-3), gaps 5/2" % (n, c["name"])
+
+    def step(self, k, stream):
+        d = self.d
+        self.pkg.align_batch_cigar_device(self.cfg, self.n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                          wl.CFG4["len"], wl.CFG4["len"], self.d_out[k % 2].data_ptr(),
+                                          self.d_text[k % 2].data_ptr(), self.cap, self.d_toff[k % 2].data_ptr(), stream.cuda_stream)
+
+    def finish(self):
+        total = int(self.d_toff[self.last_k % 2][-1].item())
+        if total > self.cap:
+            raise RuntimeError("CIGAR text capacity too small: %d > %d" % (total, self.cap))
+        self.text_bytes = total
+        self.algo_bytes = (2 * wl.CFG4["len"] + 12) * self.n + total
+
+    def pcie_inclusive(self):
+        c = wl.CFG4
+        al = self.pkg.Aligner.new().semi_global().matrix(self.matrix).gap_open(c["open"]).gap_extend(c["ext"]).solution_width(16) \
+            .use_trace().build()
+        al.align_batch_cigar_packed(*self.h)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); al.align_batch_cigar_packed(*self.h); ts.append(time.perf_counter() - t0)
+        return {"value": round(self.cells / min(ts) / 1e9, 1), "unit": "GCUPS", "ms": round(min(ts) * 1e3, 3),
+                "entry": "pmx_align_batch_cigar (host buffers in, host records + CIGAR text out)"}
+
+    def cpu_baseline(self, last_out):
+        from oracle import oracle as orc
+        c = wl.CFG4
+        om = orc.Matrix.create(c["matrix"][0], c["matrix"][1], c["matrix"][2])
+        cores = usable_cores()
+        os.environ["OMP_NUM_THREADS"] = str(cores)
+        qbuf, qoff, rbuf, roff = self.h
+        orc.cigar_sample(orc.SG, np.arange(min(self.n, 64 * cores)), qbuf, qoff, rbuf, roff, c["open"], c["ext"], om)
+        m = min(self.n, 4096 * cores)
+        t0 = time.perf_counter()
+        text, rec = orc.cigar_sample(orc.SG, np.arange(m), qbuf, qoff, rbuf, roff, c["open"], c["ext"], om)
+        t = time.perf_counter() - t0
+        v = m * c["len"] * c["len"] / t / 1e9
+        toff = self.d_toff[self.last_k % 2][: m + 1].cpu().numpy()
+        raw = self.d_text[self.last_k % 2][: int(toff[-1])].cpu().numpy().tobytes()
+        agrees = bool((last_out[:m, :3] == rec[:, :3]).all() and
+                      all(raw[toff[k]:toff[k + 1]].decode() == text[k] for k in range(m)))
+        return {"value": round(v, 3), "unit": "GCUPS", "cores": int(cores), "per_core": round(v / cores, 3), "kind": "port",
+                "sample": "the first %d pairs of the same batch, restated CPU baseline (not parasail): SCALAR Gotoh DP with a byte "
+                          "trace table + walk + CIGAR text (oracle/pmx_oracle.c, gcc -O2) under OpenMP -- no vectorised CPU port of "
+                          "the trace mode exists in this repo, so this understates parasail's striped trace kernel; %s, %.2f s wall"
+                          % (m, cpu_model(), t),
+                "agrees_with_gpu": agrees}
+
+
+class Cfg5(Workload):
+    config = 5
+    metric = "GCUPS (cell updates/s) local SW, reused 1 kbp profile vs 0.5-5 kbp references, sat (8->16->32 promotion)"
+    default_steps, default_warmup = 5, 1
+
+    def setup(self):
+        c = wl.CFG5
+        n = self.n_override or c["n"] // 8
+        strong = self.scaling == "strong" and self.world > 1
+        q, rbuf, roff, planted = wl.make_cfg5(n, rank=0 if strong else self.rank)
+        self.counts = [n] * self.world
+        if strong:
+            rl = roff[1:] - roff[:-1]
+            lo, hi, self.counts = self.shard(np.full(n, c["qlen"]), rl)
+            rbuf, roff = rbuf[roff[lo]:roff[hi]], roff[lo:hi + 1] - roff[lo]
+            n = hi - lo
+        self.n, self.q, self.h = n, q, (rbuf, roff)
+        self.d = [self.to_dev(x) for x in self.h]
+        self.d_out = [self.torch.zeros((n, 4), dtype=self.torch.int32, device=self.dev) for _ in range(2)]
+        self.matrix = self.pkg.Matrix.create(c["matrix"][0].encode(), c["matrix"][1], c["matrix"][2])
+        self.profile = self.pkg.Profile.new(q, False, self.matrix)
+        # width 0 = sat; PMX_WANT_SORTED: mixed lengths are processed in length-sorted order (records stay in input order)
+        self.cfg = self.pkg.pmx_config_t(self.pkg.MODE_SW, 0, c["open"], c["ext"], 0, self.pkg.WANT_SORTED, self.matrix.inner)
+        self.max_rlen = int((roff[1:] - roff[:-1]).max())
+        self.cells = int(c["qlen"] * roff[-1])
+        self.algo_bytes = int(roff[-1]) + 12 * n
+        self.algo_note = "reference bytes + 12 record bytes per pair (SURVEY.md 8d); the 1 kbp query is read once per workgroup"
+        self.workload = "cfg5: one 1 kbp query (reused profile) x %d references/GPU of 0.5-5 kbp (log-uniform; 1%% carry a noisy " \
+                        "copy), %s (8->16->32 promotion, none needed beyond int16 here), Matrix::create(ACGT,2,-3), gaps 5/2; " \
+                        "length sort included in the step" % (n, c["name"])
+
+    def step(self, k, stream):
+        self.pkg.align_profile_batch_device(self.cfg, self.profile, self.n, self.d[0].data_ptr(), self.d[1].data_ptr(),
+                                            self.max_rlen, self.d_out[k % 2].data_ptr(), None, stream.cuda_stream)
+
+    def cpu_baseline(self, last_out):
+        from oracle import oracle as orc
+        c = wl.CFG5
+        om = orc.Matrix.create(c["matrix"][0], c["matrix"][1], c["matrix"][2])
+        cores = usable_cores()
+        rbuf, roff = self.h
+
+        def run(m, lanes):
+            t0 = time.perf_counter()
+            out, used = orc.cpu_sw_striped16_batch(None, None, rbuf[: roff[m]], roff[: m + 1], c["open"], c["ext"], om,
+                                                   threads=cores, shared_query=self.q, lanes=lanes)
+            return time.perf_counter() - t0, used, out
+        widths = (16, 32) if orc.cpu_striped_lanes() == 32 else (16,)
+        run(min(self.n, 4 * cores), 16)
+        m0 = min(self.n, 64 * cores)
+        rate = {w: m0 / max(run(m0, w)[0], 1e-6) for w in widths}
+        lanes = max(rate, key=rate.get)
+        m = int(min(self.n, max(m0, rate[lanes] * 3.0)))
+        t, used, out = run(m, lanes)
+        v = c["qlen"] * int(roff[m]) / t / 1e9
+        agrees = bool((last_out[:m, :3] == out).all())
+        return {"value": round(v, 3), "unit": "GCUPS", "cores": int(used), "per_core": round(v / used, 3), "kind": "port",
+                "sample": "the first %d references of the same batch, restated CPU baseline (not parasail): striped int16 %s + OpenMP, "
+                          "the query profile built once per thread (oracle/pmx_striped_cpu.c), %s, %.2f s wall"
+                          % (m, "AVX-512BW x32" if lanes == 32 else "AVX2 x16", cpu_model(), t),
+                "agrees_with_gpu": agrees}
+
+
+WORKLOADS = {2: Cfg2, 3: Cfg3, 4: Cfg4, 5: Cfg5}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=N_PAIRS, help=argparse.SUPPRESS)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--pairs", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -189,32 +469,26 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    n = args.pairs
-    qbuf, qoff, rbuf, roff = make_cfg2_inputs(n, SEED + rank)     # each rank its own batch (weak scaling)
-    d_q = torch.from_numpy(qbuf).to(dev)
-    d_r = torch.from_numpy(rbuf).to(dev)
-    d_qo = torch.from_numpy(qoff).to(dev)
-    d_ro = torch.from_numpy(roff).to(dev)
-    d_out = [torch.zeros((n, 4), dtype=torch.int32, device=dev) for _ in range(2)]
-    matrix = pkg.Matrix.create(b"ACGT", MATCH, MISMATCH)
-    cfg = pkg.pmx_config_t(pkg.MODE_SW, 0, OPEN, EXT, 16, 0, matrix.inner)
+    w = WORKLOADS[args.config](pkg, torch, dev, rank, world, args.scaling, args.pairs)
+    w.setup()
+    steps = args.steps if args.steps is not None else w.default_steps
+    warmup = args.warmup if args.warmup is not None else w.default_warmup
 
     from importlib import import_module
     sharding = import_module("parasail_rs_amd.sharding")
-    counts = [n] * world
     comm_stream = torch.cuda.Stream(device=dev) if multi else None
     pending = []
 
     def step(k, events=None):
-        out = d_out[k % 2]
+        out = w.records(k)
         stream = torch.cuda.current_stream(dev)
         while len(pending) >= 2:          # the gather that last read this output buffer must be done
             fin, work = pending.pop(0)
             work.wait()
         if events is not None:
             events[0].record(stream)
-        pkg.align_batch_device(cfg, n, d_q.data_ptr(), d_qo.data_ptr(), d_r.data_ptr(), d_ro.data_ptr(),
-                               LEN, LEN, out.data_ptr(), None, stream.cuda_stream)
+        w.step(k, stream)
+        w.last_k = k
         if events is not None:
             events[1].record(stream)
         if multi:
@@ -224,9 +498,9 @@ def main():
                 done.record(stream)
                 with torch.cuda.stream(comm_stream):
                     comm_stream.wait_event(done)
-                    pending.append(sharding.gather_records(out, counts, dst=0, async_op=True))
+                    pending.append(sharding.gather_records(out, w.counts, dst=0, async_op=True))
             else:
-                pending.append(sharding.gather_records(out.cpu(), counts, dst=0, async_op=True))
+                pending.append(sharding.gather_records(out.cpu(), w.counts, dst=0, async_op=True))
 
     def drain():
         while pending:
@@ -235,70 +509,69 @@ def main():
         if comm_stream is not None:
             torch.cuda.current_stream(dev).wait_stream(comm_stream)
 
-    for k in range(args.warmup):
+    for k in range(warmup):
         step(k)
     drain()
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         step(k, evs[k])
     drain()
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    cells_all = float(w.cells)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        c = torch.tensor([cells_all], dtype=torch.float64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        cells_all = float(c.item())
+    else:
+        cells_all *= world
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if evs else float("nan")
     kernel = pkg.lib.pmx_last_kernel().decode()        # name + shape + arithmetic variant of what this thread just launched
-
-    cells_per_rank_step = n * LEN * LEN
-    total_cells = cells_per_rank_step * world * args.steps
-    gcups = total_cells / elapsed / 1e9
+    if hasattr(w, "finish"):
+        w.finish()
 
     if rank == 0:
-        achieved = ALGO_BYTES_PER_PAIR * n / (kern_ms * 1e-3) / 1e9
-        valu_peak_gcups = SIMD_CYCLES_PER_S / CYCLES_PER_128_CELLS * 128.0 / 1e9
-        kern_gcups = cells_per_rank_step / (kern_ms * 1e-3) / 1e9
+        gcups = cells_all * steps / elapsed / 1e9
+        achieved = w.algo_bytes / (kern_ms * 1e-3) / 1e9
+        kern_gcups = w.cells / (kern_ms * 1e-3) / 1e9
+        pmc = pmc_summary(args.config, kernel) if args.pairs is None and args.scaling == "weak" else None
         line = {
-            "metric": "GCUPS (cell updates/s) local-affine SW, 1M 150x150 pairs, 1/2/4/8 GPUs",
-            "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "cfg2: %d pairs/GPU x (150 bp x 150 bp) i.i.d. DNA, sw_striped_16 (score + end "
-                                   "positions), Matrix::create(ACGT,2,-3), gaps 5/2" % n,
-                       "pairs_per_gpu": n, "kernel": kernel, "inputs": "resident in HBM",
+            "metric": w.metric, "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": w.dtype, "data": "synthetic",
+            "value_is": "device-resident batch throughput (inputs already in HBM when the timed region starts, the bench contract's "
+                        "definition); SURVEY.md 8(d)'s end-to-end form (H2D + kernels + D2H through the host entry) is `pcie_inclusive`",
+            "config": {"workload": w.workload, "pairs_per_gpu": w.n, "kernel": kernel, "inputs": "resident in HBM",
                        "exchange": "none" if world == 1 else "%s gather of 16-B records to rank 0, overlapped" %
                                    ("RCCL" if backend == "nccl" else backend)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic_bytes() if n == N_PAIRS else None,
-                         "kernel_ms": round(kern_ms, 4),
-                         "note": "312 algorithmic B/pair; the path is VALU-bound, see roofline_valu"},
-            "roofline_valu": {"bound": "valu", "achieved": round(kern_gcups, 2), "peak": round(valu_peak_gcups, 1),
-                              "unit": "GCUPS", "frac": round(kern_gcups / valu_peak_gcups, 4),
-                              "model": "per 128 cells: 5.5 VOP3/VOP3P x 4 cycles + 3 VOP2 x 2 cycles = 28 SIMD cycles; "
-                                       "1024 SIMDs x 2.4 GHz (measured issue rates, profiles/r01)"},
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc.get("traffic") if pmc else None,
+                         "traffic_source": pmc.get("source") if pmc else None,
+                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": int(w.algo_bytes),
+                         "note": w.algo_note + "; the path is VALU-bound, see roofline_valu"},
         }
-        if world == 1 and not multi and n == N_PAIRS and not args.no_cpu_baseline:
+        if pmc and "lds_bank_conflict" in pmc:
+            line["lds_bank_conflict"] = dict(pmc["lds_bank_conflict"], source=pmc["source"])
+        peak, model = valu_ceiling(kernel)
+        if peak:
+            line["roofline_valu"] = {"bound": "valu", "achieved": round(kern_gcups, 2), "peak": round(peak, 1), "unit": "GCUPS",
+                                     "frac": round(kern_gcups / peak, 4), "model": model}
+        if world == 1 and not multi and args.pairs is None and not args.no_cpu_baseline and hasattr(w, "pcie_inclusive"):
             # the same batch handed over in host memory (H2D + kernels + D2H inside): reported beside, never as `value`
-            al = pkg.Aligner.new().local().matrix(matrix).gap_open(OPEN).gap_extend(EXT).solution_width(16).build()
-            al.align_batch_packed(qbuf, qoff, rbuf, roff)
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter(); al.align_batch_packed(qbuf, qoff, rbuf, roff); ts.append(time.perf_counter() - t0)
-            line["pcie_inclusive"] = {"value": round(cells_per_rank_step / min(ts) / 1e9, 1), "unit": "GCUPS",
-                                      "ms": round(min(ts) * 1e3, 3), "entry": "pmx_align_batch (pageable host buffers)"}
+            line["pcie_inclusive"] = w.pcie_inclusive()
         if world == 1 and not args.no_cpu_baseline:
-            cb, cpu_out = cpu_baseline(qbuf, qoff, rbuf, roff)
-            line["cpu_baseline"] = cb
-            got = d_out[(args.steps - 1) % 2][: len(cpu_out), :3].cpu().numpy()
-            line["cpu_baseline"]["agrees_with_gpu"] = bool((got == cpu_out).all())
+            last_out = w.records(w.last_k).cpu().numpy()
+            line["cpu_baseline"] = w.cpu_baseline(last_out)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

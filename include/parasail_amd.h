@@ -291,6 +291,20 @@ int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
                           pmx_record_t *out, char **cigar_buf, int64_t *cigar_off);
 void pmx_free(void *p);
 
+/* The same with device-resident pairs (all pointers are device pointers on the current device, the offset arrays
+ * start at 0), asynchronous on `stream`.  d_cigar_off receives n+1 offsets into d_cigar_text (the last one is the
+ * number of text bytes the batch needs); a pair whose text would cross cigar_capacity is not written, so a caller
+ * that sees d_cigar_off[n] > cigar_capacity calls again with a larger buffer.  Inside, the traceback sweep and the
+ * walk of consecutive chunks overlap on two streams.  Returns <0 when the configuration has no packed-traceback
+ * kernel (width 8, PSSM, open < extend, score + open beyond a byte, queries beyond 1023 symbols); the host entry
+ * above handles those. */
+int pmx_align_batch_cigar_device(const pmx_config_t *cfg, int64_t n,
+                                 const uint8_t *d_qbuf, const int64_t *d_qoff,
+                                 const uint8_t *d_rbuf, const int64_t *d_roff,
+                                 int32_t max_qlen, int32_t max_rlen,
+                                 pmx_record_t *d_out, char *d_cigar_text, int64_t cigar_capacity,
+                                 int64_t *d_cigar_off, void *stream);
+
 /* Runtime. */
 int pmx_device_count(void);
 int pmx_set_device(int device);            /* per calling thread, like hipSetDevice */

@@ -32,7 +32,7 @@ class _Outputs(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("pmx_oracle.c", "pmx_oracle_batch.c", "pmx_striped_cpu.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("pmx_oracle.c", "pmx_oracle_batch.c", "pmx_striped_cpu.c", "pmx_striped_body.h", "Makefile")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -53,6 +53,8 @@ def lib():
         _lib.orc_walk.restype = C.c_int
         _lib.orc_align_batch.restype = C.c_int
         _lib.pmx_cpu_sw_striped16_batch.restype = C.c_int
+        _lib.pmx_cpu_sw_striped16_batch2.restype = C.c_int
+        _lib.pmx_cpu_striped_lanes.restype = C.c_int
         _lib.orc_align_stats_sample.restype = C.c_int
         _lib.orc_cigar_sample.restype = C.c_int
         _lib.orc_rescore_cigars.restype = C.c_long
@@ -212,16 +214,30 @@ def align_batch(mode, qbuf, qoff, rbuf, roff, open_, ext, matrix, sg_flags=SG_AL
     return out
 
 
-def cpu_sw_striped16_batch(qbuf, qoff, rbuf, roff, open_, ext, matrix, threads=0):
-    """CPU timing baseline (Farrar striped int16, AVX2 + OpenMP).  Returns (out[n,3], threads_used)."""
-    n = len(qoff) - 1
+def cpu_sw_striped16_batch(qbuf, qoff, rbuf, roff, open_, ext, matrix, threads=0, shared_query=None, lanes=0):
+    """CPU timing baseline (Farrar striped int16; AVX-512BW or AVX2 picked at run time, + OpenMP).
+    shared_query: bytes of one query whose profile is built once per thread (profile arm); qbuf/qoff are ignored then.
+    lanes: 16 / 32 force a vector width (tests), 0 = what the CPU supports.  Returns (out[n,3], threads_used)."""
+    n = len(roff) - 1
     out = np.zeros((n, 3), dtype=np.int32)
-    qoff = np.ascontiguousarray(qoff, dtype=np.int64)
     roff = np.ascontiguousarray(roff, dtype=np.int64)
-    used = lib().pmx_cpu_sw_striped16_batch(C.c_long(n), _ptr(qbuf), _ptr(qoff), _ptr(rbuf), _ptr(roff),
-                                            int(open_), int(ext), _ptr(matrix.scores), matrix.size,
-                                            _ptr(matrix.mapper), _ptr(out), int(threads))
+    lib().pmx_cpu_striped_force_lanes(int(lanes))
+    if shared_query is not None:
+        qb = np.frombuffer(bytes(shared_query), dtype=np.uint8)
+        used = lib().pmx_cpu_sw_striped16_batch2(C.c_long(n), _ptr(qb), None, len(qb), _ptr(rbuf), _ptr(roff),
+                                                 int(open_), int(ext), _ptr(matrix.scores), matrix.size,
+                                                 _ptr(matrix.mapper), _ptr(out), int(threads))
+    else:
+        qoff = np.ascontiguousarray(qoff, dtype=np.int64)
+        used = lib().pmx_cpu_sw_striped16_batch2(C.c_long(n), _ptr(qbuf), _ptr(qoff), 0, _ptr(rbuf), _ptr(roff),
+                                                 int(open_), int(ext), _ptr(matrix.scores), matrix.size,
+                                                 _ptr(matrix.mapper), _ptr(out), int(threads))
+    lib().pmx_cpu_striped_force_lanes(0)
     return out, used
+
+
+def cpu_striped_lanes():
+    return int(lib().pmx_cpu_striped_lanes())
 
 
 def align_stats_sample(mode, index, qbuf, qoff, rbuf, roff, open_, ext, matrix, sg_flags=SG_ALL, bits=0, shared_query=None):

@@ -124,6 +124,8 @@ _sig("pmx_align_profile_batch_device", C.c_int, C.POINTER(pmx_config_t), C.c_voi
      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("pmx_align_batch_cigar", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
      C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p)
+_sig("pmx_align_batch_cigar_device", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+     C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 _libc_free = C.CDLL(None).free
 _libc_free.argtypes = [C.c_void_p]
 
@@ -784,6 +786,14 @@ def align_batch_device(cfg, n, d_qbuf, d_qoff, d_rbuf, d_roff, max_qlen, max_rle
     """Device-pointer entry (ints are raw device addresses, `stream` a hipStream_t value)."""
     rc = lib.pmx_align_batch_device(C.byref(cfg), n, d_qbuf, d_qoff, d_rbuf, d_roff, max_qlen, max_rlen,
                                     d_out, d_stats, stream)
+    if rc:
+        raise BatchError(lib.pmx_last_error().decode())
+
+
+def align_batch_cigar_device(cfg, n, d_qbuf, d_qoff, d_rbuf, d_roff, max_qlen, max_rlen, d_out, d_text, capacity, d_text_off, stream=0):
+    """Device-pointer CIGAR entry: records + CIGAR text + n+1 text offsets, all in device memory."""
+    rc = lib.pmx_align_batch_cigar_device(C.byref(cfg), n, d_qbuf, d_qoff, d_rbuf, d_roff, max_qlen, max_rlen,
+                                          d_out, d_text, capacity, d_text_off, stream)
     if rc:
         raise BatchError(lib.pmx_last_error().decode())
 

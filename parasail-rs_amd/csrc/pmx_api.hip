@@ -441,6 +441,7 @@ template <typename T> struct DevBuf {
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     void alloc(size_t n) { HIP_OR_DIE(hipMalloc(&p, (n ? n : 1) * sizeof(T))); }
+    int try_alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }   // entries that can report an error
 };
 
 static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Len, const char *s2, int s2Len,
@@ -967,7 +968,9 @@ extern "C" const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen,
 struct Scratch { void *p = nullptr; size_t cap = 0; int dev = -1; };
 enum { SCR_BOUND = 0, SCR_TRACE = 1, SCR_OPS = 2, SCR_SORT = 3, SCR_RETRY = 4,
        SCR_HQ = 5, SCR_HR = 6, SCR_HQO = 7, SCR_HRO = 8, SCR_HREC = 9, SCR_HST = 10,      // staging of the host-buffer batch entry
-       SCR_SLOTS = 11 };
+       SCR_CIG = 11,                                                                     // device CIGAR entry: counts, begins, text lengths, scan scratch
+       SCR_HTEXT = 12, SCR_HTOFF = 13,                                                   // staging of the host CIGAR entry
+       SCR_SLOTS = 14 };
 static thread_local Scratch g_scratch_pool[SCR_SLOTS];
 static int scratch_reserve(size_t bytes, void **out, int slot = SCR_BOUND)
 {
@@ -1272,6 +1275,108 @@ extern "C" int pmx_align_profile_batch_device(const pmx_config_t *cfg, const par
                             d_out, d_stats_out, stream, profile_has_wildcard(profile));
 }
 
+
+// ---- device-resident CIGAR entry ------------------------------------------------------------------------
+// Sweep (packed 4-bit traceback to HBM scratch) and walk run in chunks on two streams: the walk of chunk c (latency-bound, one
+// lane per pair) runs beside the sweep of chunk c + 1 (VALU-bound); the trace scratch is double-buffered.  The walk leaves
+// run-length ops in per-pair slots and each pair's text length; one scan and one render finish the batch on the caller's stream.
+struct CigarWs { hipStream_t walk = nullptr; hipEvent_t sweep_done[2] = {nullptr, nullptr}, walk_done[2] = {nullptr, nullptr}; int dev = -1; };
+static thread_local CigarWs g_cig;
+static int cigar_ws_init()
+{
+    int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
+    if (g_cig.dev == dev) return 0;
+    if (g_cig.walk) {                                   // the thread moved to another device: release the old device's objects
+        (void)hipStreamDestroy(g_cig.walk);
+        for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(g_cig.sweep_done[k]); (void)hipEventDestroy(g_cig.walk_done[k]); }
+        g_cig = CigarWs();
+    }
+    HIP_OR_RET(hipStreamCreateWithFlags(&g_cig.walk, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        HIP_OR_RET(hipEventCreateWithFlags(&g_cig.sweep_done[k], hipEventDisableTiming));
+        HIP_OR_RET(hipEventCreateWithFlags(&g_cig.walk_done[k], hipEventDisableTiming));
+    }
+    g_cig.dev = dev;
+    return 0;
+}
+
+// 0 done (asynchronously on `st`), 1 not eligible for the packed traceback sweeps, <0 error.
+// The offset arrays are absolute into d_qbuf / d_rbuf; ops_base = qoff[0] + roff[0] (0 when the offsets start at 0).
+static int cigar_device_run(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
+                            const uint8_t *d_qbuf, const int64_t *d_qoff, const uint8_t *d_rbuf, const int64_t *d_roff,
+                            int32_t mq, int32_t mr, long long ops_base,
+                            pmx_record_t *d_out, char *d_text, int64_t capacity, int64_t *d_text_off, hipStream_t st)
+{
+    if (cfg->width == 8 || cfg->matrix->type != PARASAIL_MATRIX_TYPE_SQUARE) return 1;
+    PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, mq, mr, 0, nullptr, nullptr, nullptr, 0, 0};
+    int variant = 0, Tmax = 0; size_t tbytes = 0;
+    if (pmx_trace16_plan(b, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes) != 0 || variant < 10) return 1;
+    if (cigar_ws_init()) return -1;
+    // chunks: at most ~3 GB of trace each (two buffers), at least two for the overlap once the batch is worth it
+    double chunk_bytes = 3e9;
+    if (const char *e = getenv("PMX_CIGAR_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
+    int64_t nchunks = (int64_t)((double)tbytes / chunk_bytes) + 1;
+    if (nchunks < 2 && n >= 16384) nchunks = 2;
+    int64_t chunk = ((n + nchunks - 1) / nchunks + 63) / 64 * 64;
+    if (chunk > n) chunk = n;
+    PmxBatch bc = b; bc.n = chunk;
+    size_t cbytes = 0;
+    (void)pmx_trace16_plan(bc, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &cbytes);
+    cbytes = (cbytes + 255) & ~(size_t)255;
+    const bool two = chunk < n;
+    uint32_t *tbuf = nullptr, *dops = nullptr; unsigned char *misc = nullptr;
+    const size_t scan_bytes = pmx_text_scan_scratch_bytes(n);
+    const size_t misc_bytes = (size_t)(4 * n + 2) * sizeof(int32_t) + 256 + scan_bytes;
+    if (scratch_reserve(cbytes * (two ? 2 : 1), (void **)&tbuf, SCR_TRACE) ||
+        scratch_reserve((size_t)n * ((size_t)mq + mr + 1) * sizeof(uint32_t), (void **)&dops, SCR_OPS) ||
+        scratch_reserve(misc_bytes, (void **)&misc, SCR_CIG)) return -1;
+    int32_t *nops = (int32_t *)misc, *beg = nops + n, *textlen = beg + 2 * n;
+    void *scan_tmp = (void *)(((uintptr_t)(textlen + n + 2) + 255) & ~(uintptr_t)255);
+    int idx = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += chunk, ++idx) {
+        PmxBatch bk = b;
+        bk.n = (n - c0 < chunk) ? n - c0 : chunk;
+        bk.qoff = d_qoff + c0; bk.roff = d_roff + c0;
+        if (idx >= 2) HIP_OR_RET(hipStreamWaitEvent(st, g_cig.walk_done[idx & 1], 0));     // this trace buffer's last walk is done
+        PmxWalkSplit sp = {two ? g_cig.walk : st, g_cig.sweep_done[idx & 1], two ? g_cig.walk_done[idx & 1] : nullptr,
+                           ops_base - c0, textlen + c0};
+        const int rc = pmx_launch_trace16(variant, bk, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out + c0,
+                                          (uint32_t *)((unsigned char *)tbuf + (size_t)(idx & 1) * cbytes), Tmax,
+                                          dops, nullptr, nops + c0, beg + 2 * c0, st, nullptr, &sp);
+        if (rc) { set_err("traceback launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    }
+    if (two) {
+        HIP_OR_RET(hipStreamWaitEvent(st, g_cig.walk_done[(idx - 1) & 1], 0));
+        if (idx >= 2) HIP_OR_RET(hipStreamWaitEvent(st, g_cig.walk_done[idx & 1], 0));
+    }
+    int rc = pmx_launch_text_offsets(textlen, n, d_text_off, scan_tmp, scan_bytes, st);
+    if (rc) { set_err("text offset scan failed (%d)", rc); return rc; }
+    rc = pmx_launch_cigar_render_slots(dops, d_qoff, d_roff, ops_base, nops, d_text_off, d_text, capacity, n, st);
+    if (rc) { set_err("cigar render launch failed (%d)", rc); return rc; }
+    g_last_kernel = variant >= 20 ? "pmx_sw16_kernel/packed trace + pmx_walk16_kernel" : "pmx_nwsg16v_kernel/packed trace + pmx_walk16_kernel";
+    return 0;
+}
+
+extern "C" int pmx_align_batch_cigar_device(const pmx_config_t *cfg, int64_t n,
+                                            const uint8_t *d_qbuf, const int64_t *d_qoff,
+                                            const uint8_t *d_rbuf, const int64_t *d_roff,
+                                            int32_t max_qlen, int32_t max_rlen,
+                                            pmx_record_t *d_out, char *d_cigar_text, int64_t cigar_capacity,
+                                            int64_t *d_cigar_off, void *stream)
+{
+    if (check_cfg(cfg)) return -1;
+    if (n <= 0) return 0;
+    if (!d_qbuf || !d_qoff || !d_rbuf || !d_roff || !d_out || !d_cigar_text || !d_cigar_off) { set_err("null buffer"); return -1; }
+    if (max_qlen <= 0 || max_rlen <= 0) { set_err("max_qlen / max_rlen must be positive"); return -1; }
+    DevMat dm;
+    if (get_devmat(cfg->matrix, &dm)) return -1;
+    const int rc = cigar_device_run(cfg, dm, n, d_qbuf, d_qoff, d_rbuf, d_roff, max_qlen, max_rlen, 0, d_out,
+                                    d_cigar_text, cigar_capacity, d_cigar_off, (hipStream_t)stream);
+    if (rc == 1) set_err("this configuration has no device-resident CIGAR path (width 8, PSSM, open < extend, a matrix whose score + open "
+                         "leaves a byte, or queries beyond 1023 symbols): use pmx_align_batch_cigar");
+    return rc == 1 ? -1 : rc;
+}
+
 // The caller-owned CIGAR text: a malloc block that grows chunk by chunk; device text is copied straight into it.
 struct TextBuf {
     char *p = nullptr; size_t len = 0, cap = 0;
@@ -1390,6 +1495,102 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
     return 0;
 }
 
+// Host entry on top of the device entry: the sequence bytes go up in slices on a copy stream, every slice runs the device
+// pipeline (sweep / walk overlapped inside) on a compute stream as soon as its bytes have arrived, and the host copies a finished
+// slice's records, offsets and text back while the following slices compute.  0 done, 1 not eligible, <0 error.
+static int cigar_host_pipelined(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
+                                const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
+                                pmx_record_t *out, TextBuf &text, int64_t *cigar_off)
+{
+    StageTimer tm;
+    int32_t mq = 0, mr = 0; bool bad = false;
+    host_maxlens(n, qoff, &mq, &bad); host_maxlens(n, roff, &mr, &bad);
+    if (bad) { set_err("every sequence must have length >= 1"); return -1; }
+    {   // eligibility before anything is staged
+        PmxBatch b = {nullptr, nullptr, nullptr, nullptr, n, mq, mr, 0, nullptr, nullptr, nullptr, 0, 0};
+        int variant = 0, Tmax = 0; size_t tbytes = 0;
+        if (cfg->width == 8 || pmx_trace16_plan(b, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes) != 0 || variant < 10) return 1;
+    }
+    static thread_local hipStream_t s_copy = nullptr, s_comp = nullptr;
+    static thread_local hipEvent_t s_up[8], s_done[8];
+    static thread_local int s_dev = -1;
+    int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
+    if (s_dev != dev) {
+        if (s_copy) { (void)hipStreamDestroy(s_copy); (void)hipStreamDestroy(s_comp); for (int k = 0; k < 8; ++k) { (void)hipEventDestroy(s_up[k]); (void)hipEventDestroy(s_done[k]); } }
+        HIP_OR_RET(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+        HIP_OR_RET(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
+        for (int k = 0; k < 8; ++k) {
+            HIP_OR_RET(hipEventCreateWithFlags(&s_up[k], hipEventDisableTiming));
+            HIP_OR_RET(hipEventCreateWithFlags(&s_done[k], hipEventDisableTiming));
+        }
+        s_dev = dev;
+    }
+    const int K = n >= 262144 ? 8 : n >= 32768 ? 2 : 1;
+    const size_t qbytes = (size_t)qoff[n], rbytes = (size_t)roff[n];
+    // text capacity per slice: half a byte per sequence symbol + 16 per pair covers related reads many times over; a slice
+    // that needs more is rendered again into an exact-size buffer (the ops are still in the scratch)
+    int64_t cap[8], tbase[8], lo[8], hi[8];
+    int64_t cap_total = 0;
+    for (int sl = 0; sl < K; ++sl) {
+        lo[sl] = n * sl / K; hi[sl] = n * (sl + 1) / K;
+        cap[sl] = ((qoff[hi[sl]] - qoff[lo[sl]]) + (roff[hi[sl]] - roff[lo[sl]])) / 2 + 16 * (hi[sl] - lo[sl]) + 256;
+        cap[sl] = (cap[sl] + 255) & ~(int64_t)255;
+        tbase[sl] = cap_total; cap_total += cap[sl];
+    }
+    uint8_t *dq, *dr; int64_t *dqo, *dro, *dtoff; pmx_record_t *drec; char *dtext;
+    if (scratch_reserve(qbytes, (void **)&dq, SCR_HQ) || scratch_reserve(rbytes, (void **)&dr, SCR_HR) ||
+        scratch_reserve(sizeof(int64_t) * (n + 1), (void **)&dqo, SCR_HQO) || scratch_reserve(sizeof(int64_t) * (n + 1), (void **)&dro, SCR_HRO) ||
+        scratch_reserve(sizeof(pmx_record_t) * n, (void **)&drec, SCR_HREC) ||
+        scratch_reserve((size_t)cap_total, (void **)&dtext, SCR_HTEXT) ||
+        scratch_reserve(sizeof(int64_t) * (n + K), (void **)&dtoff, SCR_HTOFF)) return -1;
+    HIP_OR_RET(hipMemcpyAsync(dqo, qoff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s_copy));
+    HIP_OR_RET(hipMemcpyAsync(dro, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s_copy));
+    for (int sl = 0; sl < K; ++sl) {
+        const int64_t a = lo[sl], e = hi[sl];
+        if (e <= a) continue;
+        HIP_OR_RET(hipMemcpyAsync(dq + qoff[a], qbuf + qoff[a], (size_t)(qoff[e] - qoff[a]), hipMemcpyHostToDevice, s_copy));
+        HIP_OR_RET(hipMemcpyAsync(dr + roff[a], rbuf + roff[a], (size_t)(roff[e] - roff[a]), hipMemcpyHostToDevice, s_copy));
+        HIP_OR_RET(hipEventRecord(s_up[sl], s_copy));
+        HIP_OR_RET(hipStreamWaitEvent(s_comp, s_up[sl], 0));
+        const int rc = cigar_device_run(cfg, dm, e - a, dq, dqo + a, dr, dro + a, mq, mr, (long long)(qoff[a] + roff[a]),
+                                        drec + a, dtext + tbase[sl], cap[sl], dtoff + a + sl, s_comp);
+        if (rc) { (void)hipStreamSynchronize(s_comp); return rc; }
+        HIP_OR_RET(hipEventRecord(s_done[sl], s_comp));
+    }
+    tm.done("queue H2D + kernels");
+    std::vector<int64_t> toff;
+    for (int sl = 0; sl < K; ++sl) {
+        const int64_t a = lo[sl], e = hi[sl], m = e - a;
+        if (m <= 0) continue;
+        HIP_OR_RET(hipEventSynchronize(s_done[sl]));
+        toff.resize((size_t)m + 1);
+        HIP_OR_RET(hipMemcpy(toff.data(), dtoff + a + sl, sizeof(int64_t) * (m + 1), hipMemcpyDeviceToHost));
+        HIP_OR_RET(hipMemcpy(out + a, drec + a, sizeof(pmx_record_t) * m, hipMemcpyDeviceToHost));
+        const int64_t total = toff[m];
+        char *dst = text.grow((size_t)total);
+        if (!dst) { (void)hipStreamSynchronize(s_comp); set_err("out of memory"); return -1; }
+        if (total > cap[sl]) {
+            // rare: the slice's text did not fit its share; every later slice has to finish first (the ops scratch is reused per slice),
+            // so redo this slice alone with an exact-size text buffer
+            HIP_OR_RET(hipStreamSynchronize(s_comp));
+            DevBuf<char> big; DevBuf<int64_t> boff;
+            if (big.try_alloc((size_t)total + 1) || boff.try_alloc((size_t)m + 1)) { set_err("out of device memory"); return -1; }
+            const int rc = cigar_device_run(cfg, dm, m, dq, dqo + a, dr, dro + a, mq, mr, (long long)(qoff[a] + roff[a]),
+                                            drec + a, big.p, total, boff.p, s_comp);
+            if (rc) return rc < 0 ? rc : -1;
+            HIP_OR_RET(hipStreamSynchronize(s_comp));
+            HIP_OR_RET(hipMemcpy(dst, big.p, (size_t)total, hipMemcpyDeviceToHost));
+        } else if (total) {
+            HIP_OR_RET(hipMemcpy(dst, dtext + tbase[sl], (size_t)total, hipMemcpyDeviceToHost));
+        }
+        const int64_t base = (int64_t)text.len;
+        for (int64_t k = 0; k < m; ++k) cigar_off[a + k + 1] = base + toff[k + 1];
+        text.len += (size_t)total;
+    }
+    tm.done("kernels + D2H");
+    return 0;
+}
+
 extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
                                      const uint8_t *qbuf, const int64_t *qoff,
                                      const uint8_t *rbuf, const int64_t *roff,
@@ -1405,6 +1606,16 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
     if (get_devmat(cfg->matrix, &dm)) return -1;
     TextBuf text;
     cigar_off[0] = 0;
+    if (!getenv("PMX_CIGAR_NO_PIPELINE")) {
+        const int rc = cigar_host_pipelined(cfg, dm, n, qbuf, qoff, rbuf, roff, out, text, cigar_off);
+        if (rc < 0) { free(text.p); return rc; }
+        if (rc == 0) {
+            if (!text.grow(0)) { set_err("out of memory"); return -1; }
+            text.p[text.len] = 0;
+            *cigar_buf = text.p;
+            return 0;
+        }
+    }
     // Chunks bound the per-launch trace scratch: budgeted at one byte per cell of the padded tables (the
     // general kernel's layout; the fast kernels write 4 bits per cell).  Large chunks matter: the walk is one
     // lane per pair and hides its dependent-load latency only with many waves in flight.  Up to 96 GB,

@@ -83,10 +83,19 @@ int pmx_launch_stats16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
 // Fast path with traceback (pmx_trace16.hip): 4-bit trace in HBM + on-device walk -> run-length ops.
 int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
                      int *variant, int *Tmax, size_t *trace_bytes);
+// Optional second stream for the walk (device CIGAR entry: the walk of chunk c runs beside the sweep of chunk c+1).
+struct PmxWalkSplit {
+    hipStream_t walk_stream;   // == the sweep's stream: no split
+    hipEvent_t sweep_done;     // recorded on the sweep stream after the sweep, awaited by the walk stream
+    hipEvent_t walk_done;      // recorded after the walk (may be null)
+    long long ops_base;        // ops_off == nullptr: slot of pair k starts at qoff[k] + roff[k] + k - ops_base
+    int32_t *textlen;          // optional, per pair: bytes of its CIGAR text
+};
 int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                        pmx_record_t *d_out, uint32_t *tbuf, int Tmax,
                        uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream,
-                       pmx_stats_t *stats_out = nullptr /* count the path's statistics instead of emitting ops */);
+                       pmx_stats_t *stats_out = nullptr /* count the path's statistics instead of emitting ops */,
+                       const PmxWalkSplit *split = nullptr);
 
 // ---- general kernel (all modes, stats, tables, rows/cols, trace, band) -------------------
 struct PmxGeneralArgs {
@@ -132,6 +141,12 @@ int pmx_launch_walk(const PmxWalkArgs &a, hipStream_t stream);
 int pmx_launch_cigar_textlen(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops, int32_t *textlen, long long n, hipStream_t stream);
 int pmx_launch_cigar_render(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops,
                             const int64_t *text_off, char *text, long long n, hipStream_t stream);
+// Device CIGAR entry: exclusive scan of the per-pair text lengths (n + 1 entries in, the last one ignored) into int64
+// offsets (n + 1 entries out, the last one = total bytes), and the render with implicit op slots and a capacity limit.
+size_t pmx_text_scan_scratch_bytes(long long n);
+int pmx_launch_text_offsets(const int32_t *textlen, long long n, int64_t *text_off, void *scratch, size_t scratch_bytes, hipStream_t stream);
+int pmx_launch_cigar_render_slots(const uint32_t *ops, const int64_t *qoff, const int64_t *roff, long long ops_base, const int32_t *nops,
+                                  const int64_t *text_off, char *text, long long capacity, long long n, hipStream_t stream);
 
 // Collect the indices of records whose flags intersect `mask`: list[0..*count) (device), any order.
 int pmx_launch_collect_saturated(const pmx_record_t *rec, long long n, int64_t *list, int *count, int mask, hipStream_t stream);

@@ -467,3 +467,35 @@ int pmx_launch_cigar_render(const uint32_t *ops, const int64_t *ops_off, const i
     return e == hipSuccess ? 0 : -(int)e;
 }
 
+
+// ---- device CIGAR entry: text offsets and render with implicit op slots ---------------------------------
+// One lane per pair: "<len><op>" per run at the pair's text offset; a pair whose text would cross `capacity` is skipped
+// (the caller sees text_off[n] > capacity).
+__global__ void pmx_cigar_render_slots_kernel(const uint32_t *ops, const int64_t *qoff, const int64_t *roff, long long ops_base,
+                                              const int32_t *nops, const int64_t *text_off, char *text, long long capacity, long long n)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (text_off[k + 1] > capacity) return;
+    const uint32_t *src = ops + (qoff[k] + roff[k] + k - ops_base);
+    char *dst = text + text_off[k];
+    const int cnt = nops[k];
+    for (int t = 0; t < cnt; ++t) {
+        const uint32_t o = src[t];
+        uint32_t v = o >> 4;
+        const int d = pmx_digits(v);
+        for (int x = d - 1; x >= 0; --x) { dst[x] = (char)('0' + v % 10); v /= 10; }
+        dst[d] = "MIDNSHP=X"[o & 0xF];
+        dst += d + 1;
+    }
+}
+
+int pmx_launch_cigar_render_slots(const uint32_t *ops, const int64_t *qoff, const int64_t *roff, long long ops_base, const int32_t *nops,
+                                  const int64_t *text_off, char *text, long long capacity, long long n, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pmx_cigar_render_slots_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream,
+                       ops, qoff, roff, ops_base, nops, text_off, text, capacity, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}

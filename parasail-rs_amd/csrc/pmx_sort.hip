@@ -38,3 +38,23 @@ int pmx_build_length_perm(const int64_t *d_roff, long long n, void *scratch, con
     *perm_out = perm;
     return 0;
 }
+
+// ---- device CIGAR entry: exclusive scan of per-pair text lengths (int32) into int64 offsets ----
+struct PmxWidenI32 { __device__ __host__ int64_t operator()(int32_t v) const { return (int64_t)v; } };
+
+size_t pmx_text_scan_scratch_bytes(long long n)
+{
+    size_t temp = 0;
+    auto in = rocprim::make_transform_iterator((const int32_t *)nullptr, PmxWidenI32());
+    (void)rocprim::exclusive_scan(nullptr, temp, in, (int64_t *)nullptr, (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), nullptr);
+    return temp + 256;
+}
+
+int pmx_launch_text_offsets(const int32_t *textlen, long long n, int64_t *text_off, void *scratch, size_t scratch_bytes, hipStream_t stream)
+{
+    auto in = rocprim::make_transform_iterator(textlen, PmxWidenI32());
+    size_t temp = scratch_bytes;
+    const hipError_t e = rocprim::exclusive_scan(scratch, temp, in, text_off, (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), stream);
+    return e == hipSuccess ? 0 : -(int)e;
+}
+

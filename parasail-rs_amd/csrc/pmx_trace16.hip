@@ -316,7 +316,8 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
                                   pmx_stats_t *stats_out /* != nullptr: count matches / similar / length along the path instead of emitting ops */,
                                   int row_pen, int col_pen /* stats: the begin gaps along the reference / query are part of the alignment */,
                                   const uint32_t *tbuf, const pmx_record_t *recs,
-                                  uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg)
+                                  uint32_t *ops, const int64_t *ops_off /* nullptr: slot of pair k starts at qoff[k] + roff[k] + k - ops_base */,
+                                  long long ops_base, int32_t *nops, int32_t *beg, int32_t *textlen /* optional: bytes of the CIGAR text */)
 {
     extern __shared__ unsigned char w_lds[];
     constexpr int QP = G * R, NP = (PACKED ? 2 : 1) * (64 / G), TW = PACKED ? 4 : R / 8;
@@ -354,15 +355,17 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
     auto nibof = [&](uint32_t w, int i) -> unsigned { return (w >> (28 - 4 * (((i + P) % R) % 8))) & 0xFu; };
     auto nib = [&](int i, int j) -> unsigned { return nibof(ldw(i, j), i); };
     const bool st = stats_out != nullptr;
-    uint32_t *o = st ? nullptr : ops + ops_off[pair];
+    uint32_t *o = st ? nullptr : ops + (ops_off ? ops_off[pair] : qb + rb + pair - ops_base);
     const pmx_record_t rec = recs[pair];
     int i = rec.end_query, j = rec.end_ref, cnt = 0;
     uint32_t cur_op = 0, cur_len = 0;
+    int tlen = 0;                    // text bytes: digits of every run length + one letter
+    auto digits = [](uint32_t v) -> int { return v < 10 ? 1 : v < 100 ? 2 : v < 1000 ? 3 : v < 10000 ? 4 : v < 100000 ? 5 : 10; };
     int nM = 0, nS = 0, nL = 0;      // statistics of the path = the coupled stats tables of the reference (same decisions, same ties)
     auto emit = [&](uint32_t op) {
         if (st) { ++nL; return; }
         if (op == cur_op) ++cur_len;
-        else { if (cur_len) o[cnt++] = (cur_len << 4) | cur_op; cur_op = op; cur_len = 1; }
+        else { if (cur_len) { o[cnt++] = (cur_len << 4) | cur_op; tlen += digits(cur_len) + 1; } cur_op = op; cur_len = 1; }
     };
     if (mode == PMX_MODE_SG && !st) {
         if (i + 1 == ql) { for (int k = rl - 1; k > j; --k) emit(OP_FOR_INS_STATE); }
@@ -397,7 +400,8 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
         }
     }
     if (st) { pmx_stats_t r3; r3.matches = nM; r3.similar = nS; r3.length = nL; stats_out[pair] = r3; return; }
-    if (cur_len) o[cnt++] = (cur_len << 4) | cur_op;
+    if (cur_len) { o[cnt++] = (cur_len << 4) | cur_op; tlen += digits(cur_len) + 1; }
+    if (textlen) textlen[pair] = tlen;
     for (int k = 0; k < cnt / 2; ++k) { const uint32_t tmp = o[k]; o[k] = o[cnt - 1 - k]; o[cnt - 1 - k] = tmp; }
     nops[pair] = cnt;
     beg[2 * pair] = i + 1; beg[2 * pair + 1] = j + 1;
@@ -435,7 +439,7 @@ static int launch_trace(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_walk16_kernel<G, R, false>), 128 * 1024); if (rc) return rc; }
     hipLaunchKernelGGL((pmx_walk16_kernel<G, R, false>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 2 * (size_t)stage, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage, 0, stats_out, row_pen, col_pen,
-                       (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg);
+                       (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, 0LL, nops, beg, (int32_t *)nullptr);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
@@ -476,7 +480,8 @@ int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int ope
 
 int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                        pmx_record_t *d_out, uint32_t *tbuf, int Tmax,
-                       uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream, pmx_stats_t *stats_out)
+                       uint32_t *ops, const int64_t *ops_off, int32_t *nops, int32_t *beg, hipStream_t stream, pmx_stats_t *stats_out,
+                       const PmxWalkSplit *split)
 {
     const bool sw = mode == PMX_MODE_SW;
     const bool sg_ = mode == PMX_MODE_SG;
@@ -487,10 +492,19 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
                      : pmx_launch_nwsgv_trace(variant - 10, b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, stream);
         if (rc) return rc;
         const int stage = walk_stage_bytes(b);
+        hipStream_t wstream = stream;
+        if (split && split->walk_stream != stream) {      // the walk runs beside the next chunk's sweep
+            hipError_t e1 = hipEventRecord(split->sweep_done, stream);
+            if (e1 == hipSuccess) e1 = hipStreamWaitEvent(split->walk_stream, split->sweep_done, 0);
+            if (e1 != hipSuccess) return -(int)e1;
+            wstream = split->walk_stream;
+        }
+        const long long ops_base = split ? split->ops_base : 0;
+        int32_t *textlen = split ? split->textlen : nullptr;
 #define WALKP(GG) { const int rca = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_walk16_kernel<GG, 16, true>), 128 * 1024); if (rca) return rca; } \
-                  hipLaunchKernelGGL((pmx_walk16_kernel<GG, 16, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 2 * (size_t)stage, stream, \
+                  hipLaunchKernelGGL((pmx_walk16_kernel<GG, 16, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 2 * (size_t)stage, wstream, \
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage, top, stats_out, row_pen_, col_pen_,     \
-                       (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, nops, beg)
+                       (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, ops_base, nops, beg, textlen)
         switch ((variant % 10) & 3) {          // lane-group size: 8, 16, 32, 64 (variants 4..7 are the matrix-lookup kernels)
         case 0: WALKP(8); break;
         case 1: WALKP(16); break;
@@ -499,8 +513,10 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
         }
 #undef WALKP
         hipError_t e = hipGetLastError();
+        if (e == hipSuccess && split && split->walk_done) e = hipEventRecord(split->walk_done, wstream);
         return e == hipSuccess ? 0 : -(int)e;
     }
+    if (split) return 1;                 // the split form is only built for the packed (second-generation) sweeps
 #define LT(GG, RR) (sw ? launch_trace<GG, RR, true>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stats_out, stream) \
                        : launch_trace<GG, RR, false>(b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, ops, ops_off, nops, beg, stats_out, stream))
     switch (variant) {

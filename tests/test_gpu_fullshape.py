@@ -186,3 +186,60 @@ def test_two_ranks_share_one_gpu_hip_path(pkg, orc):
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "dist gpu ok world=2" in p.stdout
+
+
+def test_cigar_device_entry_and_capacity(pkg, orc):
+    """pmx_align_batch_cigar_device: device pointers in, records + text + offsets in device memory; a text buffer that is
+    too small is reported through the last offset and nothing is written beyond it; local and global modes as well."""
+    import torch
+    rng = np.random.default_rng(77)
+    n = 20000
+    qbuf, qoff, rbuf, roff = wl.make_cfg4(n, rank=5)
+    rbuf = rbuf.copy()
+    rbuf[: 250 * 500] = wl.DNA[rng.integers(0, 4, size=250 * 500)]          # unrelated pairs: long CIGARs
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(x).to(dev) for x in (qbuf, qoff, rbuf, roff)]
+    out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    toff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for mode, omode in ((pkg.MODE_SG, orc.SG), (pkg.MODE_NW, orc.NW), (pkg.MODE_SW, orc.SW)):
+        cfg = pkg.pmx_config_t(mode, pkg.SG_ALL, 5, 2, 16, pkg.WANT_CIGAR, pm.inner)
+        small = torch.full((4096 + 64,), 0x55, dtype=torch.uint8, device=dev)
+        pkg.align_batch_cigar_device(cfg, n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 250, 250,
+                                     out.data_ptr(), small.data_ptr(), 4096, toff.data_ptr(), stream)
+        torch.cuda.synchronize()
+        need = int(toff[-1].item())
+        assert need > 4096 and (small[4096:] == 0x55).all()                 # reported, and nothing written past the capacity
+        text = torch.zeros(need, dtype=torch.uint8, device=dev)
+        pkg.align_batch_cigar_device(cfg, n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 250, 250,
+                                     out.data_ptr(), text.data_ptr(), need, toff.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert int(toff[-1].item()) == need
+        o, t = toff.cpu().numpy(), text.cpu().numpy().tobytes()
+        rec = out.cpu().numpy()
+        idx = np.concatenate([np.arange(0, 500, 7), np.arange(500, n, 97)])
+        want_text, want = orc.cigar_sample(omode, idx, qbuf, qoff, rbuf, roff, 5, 2, om)
+        for k, i in enumerate(idx):
+            assert tuple(rec[i, :3]) == tuple(want[k, :3]), (mode, i)
+            assert t[o[i]:o[i + 1]].decode() == want_text[k], (mode, i)
+        res, malformed = orc.rescore_cigars(np.frombuffer(t, dtype=np.uint8), o, qbuf, qoff, rbuf, roff, 5, 2, om,
+                                            free_mask=orc.SG_ALL if omode == orc.SG else 0,
+                                            beg=None if omode != orc.SW else _sw_begins(rec, res=None, o=o, t=t, n=n))
+        assert malformed == 0 and (res[:, 3] == 0).all() and (res[:, 0] == rec[:, 0]).all()
+
+
+def _sw_begins(rec, res, o, t, n):
+    """Local alignments: begin = end + 1 - symbols the CIGAR consumes on each side."""
+    import re
+    beg = np.zeros((n, 2), dtype=np.int32)
+    for k in range(n):
+        qc = rc = 0
+        for cnt, op in re.findall(r"(\d+)([=XID])", t[o[k]:o[k + 1]].decode()):
+            c = int(cnt)
+            if op in "=XI":
+                qc += c
+            if op in "=XD":
+                rc += c
+        beg[k] = (rec[k, 1] + 1 - qc, rec[k, 2] + 1 - rc)
+    return beg

@@ -145,9 +145,10 @@ def test_striped_cpu_port_matches_scalar(orc, gaps):
     rs = [mutate(rng, q, 0.1, 0.05) if rng.random() < 0.6 else random_seqs(rng, 1, 1, 200)[0] for q in qs]
     qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
     want = orc.align_batch(orc.SW, qb, qo, rb, ro, gaps[0], gaps[1], m)
-    got, used = orc.cpu_sw_striped16_batch(qb, qo, rb, ro, gaps[0], gaps[1], m, threads=2)
-    assert used >= 1
-    assert (got == want).all()
+    for lanes in (16, 32) if orc.cpu_striped_lanes() == 32 else (16,):      # both vector widths where the CPU has AVX-512BW
+        got, used = orc.cpu_sw_striped16_batch(qb, qo, rb, ro, gaps[0], gaps[1], m, threads=2, lanes=lanes)
+        assert used >= 1
+        assert (got == want).all(), lanes
 
 
 def test_striped_cpu_port_blosum62(orc):
@@ -159,6 +160,13 @@ def test_striped_cpu_port_blosum62(orc):
     want = orc.align_batch(orc.SW, qb, qo, rb, ro, 11, 1, m)
     got, _ = orc.cpu_sw_striped16_batch(qb, qo, rb, ro, 11, 1, m, threads=2)
     assert (got == want).all()
+    # profile arm: one shared query, its striped profile built once per thread
+    q = qs[7]
+    qb2, qo2 = orc.pack([q] * len(rs))
+    want = orc.align_batch(orc.SW, qb2, qo2, rb, ro, 11, 1, m)
+    for lanes in (16, 32) if orc.cpu_striped_lanes() == 32 else (16,):
+        got, _ = orc.cpu_sw_striped16_batch(None, None, rb, ro, 11, 1, m, threads=2, shared_query=q, lanes=lanes)
+        assert (got == want).all(), lanes
 
 
 def test_cfg1_fixture_is_reproduced(orc):
