@@ -767,9 +767,37 @@ class Aligner:
                                        roff.ctypes.data, out.ctypes.data, C.byref(cbuf), coff.ctypes.data)
         if rc:
             raise BatchError(lib.pmx_last_error().decode())
-        text = np.frombuffer(C.string_at(cbuf, int(coff[n])), dtype=np.uint8)
-        lib.pmx_free(cbuf)
+        # a view of the callee's malloc block (no copy); released with pmx_free when the array goes away
+        nbytes = int(coff[n])
+        holder = _OwnedBuffer(cbuf)
+        text = np.frombuffer((C.c_ubyte * max(nbytes, 1)).from_address(cbuf.value), dtype=np.uint8, count=nbytes)
+        text = _with_owner(text, holder)
         return out, text, coff
+
+
+class _OwnedBuffer:
+    """Keeps a callee-allocated block alive for numpy views of it; pmx_free on collection."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib.pmx_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class _OwnedArray(np.ndarray):
+    pass
+
+
+def _with_owner(arr, owner):
+    out = arr.view(_OwnedArray)
+    out._pmx_owner = owner
+    return out
 
 
 def pack(seqs):

@@ -1291,7 +1291,10 @@ static int cigar_ws_init()
         for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(g_cig.sweep_done[k]); (void)hipEventDestroy(g_cig.walk_done[k]); }
         g_cig = CigarWs();
     }
-    HIP_OR_RET(hipStreamCreateWithFlags(&g_cig.walk, hipStreamNonBlocking));
+    // the walk gets the higher priority: its few, latency-bound workgroups slip in between the sweep's as those retire
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    HIP_OR_RET(hipStreamCreateWithPriority(&g_cig.walk, hipStreamNonBlocking, prio_hi));
     for (int k = 0; k < 2; ++k) {
         HIP_OR_RET(hipEventCreateWithFlags(&g_cig.sweep_done[k], hipEventDisableTiming));
         HIP_OR_RET(hipEventCreateWithFlags(&g_cig.walk_done[k], hipEventDisableTiming));

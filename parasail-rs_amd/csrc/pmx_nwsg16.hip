@@ -64,6 +64,12 @@ __device__ __forceinline__ int n_bfi(int m, int a, int b)
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ int s_bfi(int m /* scalar constant */, int a, int b)
+{
+    int r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(m), "v"(a), "v"(b));
+    return r;
+}
 // per-half masks (0xFFFF / 0) on values below 32768
 __device__ __forceinline__ int m_lt(v2s a, v2s b) { const v2s sh = {15, 15}; return I32((a - b) >> sh); }      // a < b
 __device__ __forceinline__ int m_eq(v2s a, v2s b)
@@ -382,9 +388,12 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
 //     decision is the sign of one packed difference, pushed into a packed plane (16 bits = 4 rows per
 //     half): 3 instructions per decision and 2 cells.  Per lane and step one 16-byte store, coalesced over the
 //     wave: [pair A rows 0-7, A rows 8-15, B rows 0-7, B rows 8-15], row 0 in the top nibble.  
+//     TRB (the host proves max score + 2 open <= 250): every one of the four differences lies in [-256, 255], so its sign fills
+//     bits 15..8 of its half and a decision is inserted at ITS bit position with one v_bfi_b32 -- no shift: two rows' eight
+//     decisions chain through one register (4 v_pk_sub_i16 + 3.5 v_bfi_b32 per row), one v_perm_b32 per four rows packs the top bytes.
 //   * FETCH (long references): reference symbols are not staged in LDS, each lane fetches its next symbols from HBM
 //     two steps ahead (see pmx_sw16q.hip); the staged copies of four 5-kaa references would halve the occupancy.
-template <int G, int R, bool TR, bool FETCH = false>
+template <int G, int R, bool TR, bool FETCH = false, bool TRB = false>
 __global__ __launch_bounds__(64)
 void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                         const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
@@ -534,7 +543,11 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 #pragma unroll
         for (int k = 0; k < RS / 4; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
     };
-    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * Tmax) * 256 + lane * 4 : nullptr;
+    // trace records of 16 bytes per lane and step; Tmax < 0 selects the lane-major layout (every lane's steps contiguous: what the
+    // walk reads along a row or a diagonal sits in one cache line), Tmax > 0 the step-major one (a wave's step contiguous)
+    const int TmaxA = Tmax < 0 ? -Tmax : Tmax;
+    const size_t t_ls = Tmax < 0 ? (size_t)TmaxA * 4 : 4, t_ss = Tmax < 0 ? 4 : 256;
+    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * TmaxA) * 256 + (size_t)lane * t_ls : nullptr;
     const v2s two2 = {2, 2}, sh15 = {15, 15};
     auto push = [&](v2s &pl, int a, int b) {         // pl = 2 * pl + (a < b), per half
         const v2s bit = PK(I32(__builtin_bit_cast(v2us, PK(a) - PK(b)) >> __builtin_bit_cast(v2us, sh15)));
@@ -547,6 +560,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         int F = n_shift_up<G, IL>(Fout, topX, g);            // F^ into row 0 = X of the row above (see the header)
         int Tpre[R];
         v2s plane[TR ? R / 4 : 1];
+        int tacc = 0, tprev = 0;
         if (TR) {
 #pragma unroll
             for (int x = 0; x < R / 4; ++x) plane[x] = PK(0);
@@ -562,11 +576,29 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             const int Fe = F - vExt;
             const int H = I32(n_max3f(PK(Tpre[k]), PK(E[k]), PK(Fe)));
             const int X = H - vC;
-            if (TR) {
+            if (TR && !TRB) {
                 push(plane[k / 4], Tpre[k], H);      // ND
                 push(plane[k / 4], Fe, H);           // NDL
                 push(plane[k / 4], E[k], X);         // EO: E(j) - ext < H - open in the skewed forms
                 push(plane[k / 4], Fe, X);           // FO: F - ext < H - open
+            }
+            if (TR && TRB) {
+                // sign of (a - b) at bit `pos` of each half; differences are within [-256, 255] (see the header)
+                const int dND = I32(PK(Tpre[k]) - PK(H)), dNDL = I32(PK(Fe) - PK(H));
+                const int dEO = I32(PK(E[k]) - PK(X)), dFO = I32(PK(Fe) - PK(X));
+                if ((k & 1) == 0) {
+                    tacc = dND;                                                   // bit 15 (the rest is replaced below)
+                    tacc = s_bfi(0x40004000, dNDL, tacc);
+                    tacc = s_bfi(0x20002000, dEO, tacc);
+                    tacc = s_bfi(0x10001000, dFO, tacc);
+                } else {
+                    tacc = s_bfi(0x08000800, dND, tacc);
+                    tacc = s_bfi(0x04000400, dNDL, tacc);
+                    tacc = s_bfi(0x02000200, dEO, tacc);
+                    tacc = s_bfi(0x01000100, dFO, tacc);
+                    if ((k & 3) == 1) tprev = tacc;                              // rows 4x, 4x+1
+                    else plane[k / 4] = PK(__builtin_amdgcn_perm(tprev, tacc, 0x07030501));   // + rows 4x+2, 4x+3: top bytes of the halves
+                }
             }
             E[k] = I32(n_max3f(PK(E[k]), PK(X), PK(X)));
             F = I32(n_max3f(PK(Fe), PK(X), PK(X)));
@@ -574,11 +606,11 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         }
         if (TR) {
             uint4 w;
-            w.x = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x05040100);   // A: rows 0-3 | rows 4-7
-            w.y = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x05040100);
-            w.z = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x07060302);   // B
-            w.w = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x07060302);
-            *reinterpret_cast<uint4 *>(tw + (size_t)t * 256) = w;
+            w.x = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x00010405);   // A: bytes = row pairs (0,1) (2,3) (4,5) (6,7), even row in the high nibble
+            w.y = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x00010405);
+            w.z = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x02030607);   // B
+            w.w = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x02030607);
+            *reinterpret_cast<uint4 *>(tw + (size_t)t * t_ss) = w;
         }
         diag0 = Hin;
         Hout = Hnew[R - 1];
@@ -1026,7 +1058,11 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             w[bsel][k] = sa | (sb << 16);
         }
     };
-    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * Tmax) * 256 + lane * 4 : nullptr;
+    // trace records of 16 bytes per lane and step; Tmax < 0 selects the lane-major layout (every lane's steps contiguous: what the
+    // walk reads along a row or a diagonal sits in one cache line), Tmax > 0 the step-major one (a wave's step contiguous)
+    const int TmaxA = Tmax < 0 ? -Tmax : Tmax;
+    const size_t t_ls = Tmax < 0 ? (size_t)TmaxA * 4 : 4, t_ss = Tmax < 0 ? 4 : 256;
+    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * TmaxA) * 256 + (size_t)lane * t_ls : nullptr;
     auto push = [&](int &pl, int a, int b) {          // pl = 2 * pl + (a < b), per half
         const v2us fifteen = {15, 15};
         const int bit = I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, PK(a) - PK(b)) >> fifteen));
@@ -1065,11 +1101,11 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         }
         if (TR) {
             uint4 w4;
-            w4.x = __builtin_amdgcn_perm(plane[0], plane[1], 0x05040100);
-            w4.y = __builtin_amdgcn_perm(plane[2], plane[3], 0x05040100);
-            w4.z = __builtin_amdgcn_perm(plane[0], plane[1], 0x07060302);
-            w4.w = __builtin_amdgcn_perm(plane[2], plane[3], 0x07060302);
-            *reinterpret_cast<uint4 *>(tw + (size_t)t * 256) = w4;
+            w4.x = __builtin_amdgcn_perm(plane[0], plane[1], 0x00010405);
+            w4.y = __builtin_amdgcn_perm(plane[2], plane[3], 0x00010405);
+            w4.z = __builtin_amdgcn_perm(plane[0], plane[1], 0x02030607);
+            w4.w = __builtin_amdgcn_perm(plane[2], plane[3], 0x02030607);
+            *reinterpret_cast<uint4 *>(tw + (size_t)t * t_ss) = w4;
         }
         diag0 = Hin;
         Hout = X[R - 1];
@@ -1233,22 +1269,24 @@ static int launch_nwsg(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
     return e == hipSuccess ? 0 : -(int)e;
 }
 
-template <int G, int R, bool TR = false, bool FETCH = false>
+template <int G, int R, bool TR = false, bool FETCH = false, bool TRB = false>
 static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
                         pmx_record_t *d_out, hipStream_t stream, uint32_t *tbuf = nullptr, int Tmax = 0)
 {
+    if (TR && !TRB && (m.max > 0 ? m.max : 0) + 2 * open <= 250 && !getenv("PMX_TRACE_NO_BFI"))     // bounded differences: the one-instruction merge
+        return launch_nwsgv<G, R, TR, FETCH, TR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     constexpr int RS = (R + 3) / 4 * 4, NP = 2 * (64 / G);
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
     const size_t lds = (size_t)NP * (m.msize + 1) * G * RS + (FETCH ? 0 : (size_t)NP * RP) +
                        (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40;
     if (lds > 160 * 1024) return 1;
-    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R, TR, FETCH>)); if (rc) return rc; }
+    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R, TR, FETCH, TRB>)); if (rc) return rc; }
     const bool sg = mode == PMX_MODE_SG;
     const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, FETCH>), dim3((unsigned)blocks), dim3(64), lds, stream,
+    hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, FETCH, TRB>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                        m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax);
     hipError_t e = hipGetLastError();

@@ -326,7 +326,11 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 #pragma unroll
         for (int k = 0; k < RS / WR; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
     };
-    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * Tmax) * 256 + lane * 4 : nullptr;
+    // trace records of 16 bytes per lane and step; Tmax < 0 selects the lane-major layout (every lane's steps contiguous: what the
+    // walk reads along a row or a diagonal sits in one cache line), Tmax > 0 the step-major one (a wave's step contiguous)
+    const int TmaxA = Tmax < 0 ? -Tmax : Tmax;
+    const size_t t_ls = Tmax < 0 ? (size_t)TmaxA * 4 : 4, t_ss = Tmax < 0 ? 4 : 256;
+    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * TmaxA) * 256 + (size_t)lane * t_ls : nullptr;
     auto push = [&](v2s &pl, v2s a, v2s b) {        // pl = 2 * pl + (a < b), per half
         const v2u fifteen = {15, 15};
         const int bit = I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2u, a - b) >> fifteen));
@@ -420,11 +424,11 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         }
         if (TR) {
             uint4 w;
-            w.x = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x05040100);   // A: rows 0-3 | rows 4-7
-            w.y = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x05040100);
-            w.z = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x07060302);   // B
-            w.w = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x07060302);
-            *reinterpret_cast<uint4 *>(tw + (size_t)t * 256) = w;
+            w.x = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x00010405);   // A: bytes = row pairs (0,1) (2,3) (4,5) (6,7), even row in the high nibble
+            w.y = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x00010405);
+            w.z = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x02030607);   // B
+            w.w = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x02030607);
+            *reinterpret_cast<uint4 *>(tw + (size_t)t * t_ss) = w;
         }
         diag0 = PK(Hin);
         Hout = I32(Hnew[R - 1]);

@@ -131,7 +131,11 @@ void pmx_sw16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
             w[bsel][k] = sa | (sb << 16);
         }
     };
-    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * Tmax) * 256 + lane * 4 : nullptr;
+    // trace records of 16 bytes per lane and step; Tmax < 0 selects the lane-major layout (every lane's steps contiguous: what the
+    // walk reads along a row or a diagonal sits in one cache line), Tmax > 0 the step-major one (a wave's step contiguous)
+    const int TmaxA = Tmax < 0 ? -Tmax : Tmax;
+    const size_t t_ls = Tmax < 0 ? (size_t)TmaxA * 4 : 4, t_ss = Tmax < 0 ? 4 : 256;
+    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * TmaxA) * 256 + (size_t)lane * t_ls : nullptr;
     auto push = [&](int &pl, int a, int b) {          // pl = 2 * pl + (a < b), per half
         typedef unsigned short u2 __attribute__((ext_vector_type(2)));
         const u2 fifteen = {15, 15};
@@ -174,11 +178,11 @@ void pmx_sw16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
         }
         if (TR) {
             uint4 w4;
-            w4.x = __builtin_amdgcn_perm(plane[0], plane[1], 0x05040100);
-            w4.y = __builtin_amdgcn_perm(plane[2], plane[3], 0x05040100);
-            w4.z = __builtin_amdgcn_perm(plane[0], plane[1], 0x07060302);
-            w4.w = __builtin_amdgcn_perm(plane[2], plane[3], 0x07060302);
-            *reinterpret_cast<uint4 *>(tw + (size_t)t * 256) = w4;
+            w4.x = __builtin_amdgcn_perm(plane[0], plane[1], 0x00010405);
+            w4.y = __builtin_amdgcn_perm(plane[2], plane[3], 0x00010405);
+            w4.z = __builtin_amdgcn_perm(plane[0], plane[1], 0x02030607);
+            w4.w = __builtin_amdgcn_perm(plane[2], plane[3], 0x02030607);
+            *reinterpret_cast<uint4 *>(tw + (size_t)t * t_ss) = w4;
         }
         diag0 = Hin;
         Hout = X[R - 1];

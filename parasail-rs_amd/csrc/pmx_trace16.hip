@@ -344,15 +344,22 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
     const uint8_t *q = qbuf + qb, *r = rbuf + rb;
     const unsigned char *sq = w_lds + (qb - qlo), *sr = w_lds + stage + (rb - rlo);
     const long long block = pair / NP; const int slot = (int)(pair % NP);
-    const uint32_t *tb = tbuf + (size_t)block * Tmax * (64 * TW);
+    // PACKED: records of 16 bytes per lane and step -- byte b of a record: half (slot & 1) * 8 + row-in-lane / 2, the even row in the
+    // high nibble; Tmax < 0: lane-major (a lane's steps contiguous), else step-major.  Unpacked: R / 8 words per lane and step.
+    const int TmaxA = Tmax < 0 ? -Tmax : Tmax;
+    const uint32_t *tb = tbuf + (size_t)block * TmaxA * (64 * TW);
+    const size_t t_ls = Tmax < 0 ? (size_t)TmaxA * 4 : 4, t_ss = Tmax < 0 ? 4 : 256;
     const int P = top_aligned ? 0 : QP - ql;
     auto ldw = [&](int i, int j) -> uint32_t {         // the trace word holding cell (i, j); 0 outside i >= -1, j >= 0
         if (i < -1 || j < 0) return 0u;
         const int er = i + P, g = er / R, k = er % R;
-        return PACKED ? tb[(size_t)(j + g) * 256 + ((slot >> 1) * G + g) * 4 + (slot & 1) * 2 + (k / 8)]
+        return PACKED ? tb[(size_t)(j + g) * t_ss + (size_t)((slot >> 1) * G + g) * t_ls + (slot & 1) * 2 + (k / 8)]
                       : tb[(size_t)(j + g) * (64 * TW) + (slot * G + g) * TW + (k / 8)];
     };
-    auto nibof = [&](uint32_t w, int i) -> unsigned { return (w >> (28 - 4 * (((i + P) % R) % 8))) & 0xFu; };
+    auto nibof = [&](uint32_t w, int i) -> unsigned {
+        const int k8 = ((i + P) % R) % 8;
+        return PACKED ? (w >> (8 * (k8 >> 1) + ((k8 & 1) ? 0 : 4))) & 0xFu : (w >> (28 - 4 * k8)) & 0xFu;
+    };
     auto nib = [&](int i, int j) -> unsigned { return nibof(ldw(i, j), i); };
     const bool st = stats_out != nullptr;
     uint32_t *o = st ? nullptr : ops + (ops_off ? ops_off[pair] : qb + rb + pair - ops_base);
@@ -488,6 +495,8 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
     const int col_pen_ = sw ? 0 : !(sg_ && (sg_flags & PMX_SG_QB)), row_pen_ = sw ? 0 : !(sg_ && (sg_flags & PMX_SG_DB));
     if (variant >= 10) {
         const int top = variant >= 20 ? 1 : 0;
+        static const bool step_major = [] { const char *e = getenv("PMX_TRACE_LAYOUT"); return e && e[0] == 's'; }();
+        Tmax = step_major ? Tmax : -Tmax;               // sign = layout, for the sweep and for the walk
         int rc = top ? pmx_launch_sw16_trace(variant - 20, b, m, open, ext, d_out, tbuf, Tmax, stream)
                      : pmx_launch_nwsgv_trace(variant - 10, b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, stream);
         if (rc) return rc;
