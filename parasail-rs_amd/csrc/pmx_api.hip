@@ -1326,7 +1326,7 @@ static int cigar_device_run(const pmx_config_t *cfg, const DevMat &dm, int64_t n
     size_t cbytes = 0;
     (void)pmx_trace16_plan(bc, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &cbytes);
     cbytes = (cbytes + 255) & ~(size_t)255;
-    const bool two = chunk < n;
+    const bool two = chunk < n && !getenv("PMX_CIGAR_NO_OVERLAP");     // (diagnostics: sweep and walk back to back on one stream)
     uint32_t *tbuf = nullptr, *dops = nullptr; unsigned char *misc = nullptr;
     const size_t scan_bytes = pmx_text_scan_scratch_bytes(n);
     const size_t misc_bytes = (size_t)(4 * n + 2) * sizeof(int32_t) + 256 + scan_bytes;
@@ -1340,11 +1340,11 @@ static int cigar_device_run(const pmx_config_t *cfg, const DevMat &dm, int64_t n
         PmxBatch bk = b;
         bk.n = (n - c0 < chunk) ? n - c0 : chunk;
         bk.qoff = d_qoff + c0; bk.roff = d_roff + c0;
-        if (idx >= 2) HIP_OR_RET(hipStreamWaitEvent(st, g_cig.walk_done[idx & 1], 0));     // this trace buffer's last walk is done
+        if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(st, g_cig.walk_done[idx & 1], 0));     // this trace buffer's last walk is done
         PmxWalkSplit sp = {two ? g_cig.walk : st, g_cig.sweep_done[idx & 1], two ? g_cig.walk_done[idx & 1] : nullptr,
                            ops_base - c0, textlen + c0};
         const int rc = pmx_launch_trace16(variant, bk, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out + c0,
-                                          (uint32_t *)((unsigned char *)tbuf + (size_t)(idx & 1) * cbytes), Tmax,
+                                          (uint32_t *)((unsigned char *)tbuf + (two ? (size_t)(idx & 1) * cbytes : 0)), Tmax,
                                           dops, nullptr, nops + c0, beg + 2 * c0, st, nullptr, &sp);
         if (rc) { set_err("traceback launch failed (%d)", rc); return rc < 0 ? rc : -1; }
     }
@@ -1436,7 +1436,7 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
     int variant = 0, Tmax = 0; size_t tbytes = 0;
     int rc;
     if (cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&
-        pmx_trace16_plan(b, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes) == 0) {
+        pmx_trace16_plan(b, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes, false) == 0) {   // (packed sweeps: the pipelined path)
         uint32_t *tbuf = nullptr;
         if (scratch_reserve(tbytes, (void **)&tbuf, SCR_TRACE)) return -1;
         rc = pmx_launch_trace16(variant, b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, drec.p, tbuf, Tmax,
@@ -1609,7 +1609,7 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
     if (get_devmat(cfg->matrix, &dm)) return -1;
     TextBuf text;
     cigar_off[0] = 0;
-    if (!getenv("PMX_CIGAR_NO_PIPELINE")) {
+    {
         const int rc = cigar_host_pipelined(cfg, dm, n, qbuf, qoff, rbuf, roff, out, text, cigar_off);
         if (rc < 0) { free(text.p); return rc; }
         if (rc == 0) {

@@ -82,7 +82,13 @@ int pmx_launch_stats16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
 
 // Fast path with traceback (pmx_trace16.hip): 4-bit trace in HBM + on-device walk -> run-length ops.
 int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
-                     int *variant, int *Tmax, size_t *trace_bytes);
+                     int *variant, int *Tmax, size_t *trace_bytes, bool packed_ok = true /* false: first-generation kernels only */);
+// Walk over the packed records (pmx_walkp.hip).  ops: run-length BAM ops written from the END of the pair's slot backwards
+// (slot = ops_off[k] .. + qlen + rlen + 1, or implicit: qoff[k] + roff[k] + k - ops_base): the forward list is the last nops[k] entries.
+int pmx_launch_walkp(int gsel, int R, const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext, int Tmax, int top_aligned,
+                     pmx_stats_t *stats_out, int row_pen, int col_pen, const uint32_t *tbuf, const pmx_record_t *recs,
+                     uint32_t *ops, const int64_t *ops_off, long long ops_base, int32_t *nops, int32_t *beg, int32_t *textlen,
+                     hipStream_t stream);
 // Optional second stream for the walk (device CIGAR entry: the walk of chunk c runs beside the sweep of chunk c+1).
 struct PmxWalkSplit {
     hipStream_t walk_stream;   // == the sweep's stream: no split

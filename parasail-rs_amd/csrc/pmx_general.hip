@@ -469,24 +469,35 @@ int pmx_launch_cigar_render(const uint32_t *ops, const int64_t *ops_off, const i
 
 
 // ---- device CIGAR entry: text offsets and render with implicit op slots ---------------------------------
-// One lane per pair: "<len><op>" per run at the pair's text offset; a pair whose text would cross `capacity` is skipped
+// Eight lanes per pair: every lane renders one run per round ("<len><op>"), its text position is the group's running
+// base plus a prefix sum of the widths over the eight lanes.  A pair whose text would cross `capacity` is skipped
 // (the caller sees text_off[n] > capacity).
 __global__ void pmx_cigar_render_slots_kernel(const uint32_t *ops, const int64_t *qoff, const int64_t *roff, long long ops_base,
                                               const int32_t *nops, const int64_t *text_off, char *text, long long capacity, long long n)
 {
-    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long k = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int l = threadIdx.x & 7;
     if (k >= n) return;
     if (text_off[k + 1] > capacity) return;
-    const uint32_t *src = ops + (qoff[k] + roff[k] + k - ops_base);
-    char *dst = text + text_off[k];
     const int cnt = nops[k];
-    for (int t = 0; t < cnt; ++t) {
-        const uint32_t o = src[t];
+    // the walk fills a pair's slot of qlen + rlen + 1 entries from its end backwards: the forward list is its last cnt entries
+    const uint32_t *src = ops + (qoff[k + 1] + roff[k + 1] + k + 1 - ops_base) - cnt;
+    long long base = text_off[k];
+    for (int t0 = 0; t0 < cnt; t0 += 8) {
+        const int t = t0 + l;
+        const uint32_t o = t < cnt ? src[t] : 0u;
         uint32_t v = o >> 4;
         const int d = pmx_digits(v);
-        for (int x = d - 1; x >= 0; --x) { dst[x] = (char)('0' + v % 10); v /= 10; }
-        dst[d] = "MIDNSHP=X"[o & 0xF];
-        dst += d + 1;
+        const int w = t < cnt ? d + 1 : 0;
+        int inc = w;
+#pragma unroll
+        for (int s = 1; s < 8; s <<= 1) { const int up = __shfl_up(inc, s, 8); if (l >= s) inc += up; }
+        if (t < cnt) {
+            char *dst = text + base + inc - w;
+            for (int x = d - 1; x >= 0; --x) { dst[x] = (char)('0' + v % 10); v /= 10; }
+            dst[d] = "MIDNSHP=X"[o & 0xF];
+        }
+        base += __shfl(inc, 7, 8);
     }
 }
 
@@ -494,7 +505,7 @@ int pmx_launch_cigar_render_slots(const uint32_t *ops, const int64_t *qoff, cons
                                   const int64_t *text_off, char *text, long long capacity, long long n, hipStream_t stream)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(pmx_cigar_render_slots_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream,
+    hipLaunchKernelGGL(pmx_cigar_render_slots_kernel, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, stream,
                        ops, qoff, roff, ops_base, nops, text_off, text, capacity, n);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;

@@ -326,11 +326,10 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
 #pragma unroll
         for (int k = 0; k < RS / WR; ++k) { wa[k] = sa[k]; wb[k] = sb[k]; }
     };
-    // trace records of 16 bytes per lane and step; Tmax < 0 selects the lane-major layout (every lane's steps contiguous: what the
-    // walk reads along a row or a diagonal sits in one cache line), Tmax > 0 the step-major one (a wave's step contiguous)
-    const int TmaxA = Tmax < 0 ? -Tmax : Tmax;
-    const size_t t_ls = Tmax < 0 ? (size_t)TmaxA * 4 : 4, t_ss = Tmax < 0 ? 4 : 256;
-    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * TmaxA) * 256 + (size_t)lane * t_ls : nullptr;
+    // trace records of 16 bytes per lane and step, lane-major: every lane's steps are contiguous, so what the walk reads along a row
+    // or a diagonal sits in one cache line (consecutive stores of a lane fill its 128-byte lines in L2)
+    const size_t t_ss = 4;
+    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * Tmax) * 256 + (size_t)lane * Tmax * 4 : nullptr;
     auto push = [&](v2s &pl, v2s a, v2s b) {        // pl = 2 * pl + (a < b), per half
         const v2u fifteen = {15, 15};
         const int bit = I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2u, a - b) >> fifteen));
@@ -598,7 +597,7 @@ int pmx_sw16_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int open, int 
         int G = 0;
         for (int v = 1; v < 4 && !G; ++v) if (b.max_qlen <= (8 << v) * 16) { *variant = 4 + v; G = 8 << v; }
         if (!G) return 1;
-        *Tmax = (b.max_rlen + G - 1 + 1) & ~1;          // that kernel sweeps an even number of steps
+        *Tmax = (b.max_rlen + G - 1 + 1 + 15) & ~15;    // that kernel sweeps an even number of steps; the walk reads windows of 16
         *trace_bytes = (size_t)((b.n + 2 * (64 / G) - 1) / (2 * (64 / G))) * (size_t)*Tmax * 64 * 16;
         return 0;
     }
@@ -611,7 +610,7 @@ int pmx_sw16_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int open, int 
     }
     if (!G) return 1;
     const int NP = 2 * (64 / G);
-    *Tmax = b.max_rlen + G - 1;
+    *Tmax = (b.max_rlen + G - 1 + 15) & ~15;        // multiple of 16: the walk reads a lane's records in windows of 16
     *trace_bytes = (size_t)((b.n + NP - 1) / NP) * (size_t)*Tmax * 64 * 16;
     return 0;
 }

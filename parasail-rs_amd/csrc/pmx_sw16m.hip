@@ -131,11 +131,10 @@ void pmx_sw16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
             w[bsel][k] = sa | (sb << 16);
         }
     };
-    // trace records of 16 bytes per lane and step; Tmax < 0 selects the lane-major layout (every lane's steps contiguous: what the
-    // walk reads along a row or a diagonal sits in one cache line), Tmax > 0 the step-major one (a wave's step contiguous)
-    const int TmaxA = Tmax < 0 ? -Tmax : Tmax;
-    const size_t t_ls = Tmax < 0 ? (size_t)TmaxA * 4 : 4, t_ss = Tmax < 0 ? 4 : 256;
-    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * TmaxA) * 256 + (size_t)lane * t_ls : nullptr;
+    // trace records of 16 bytes per lane and step, lane-major: every lane's steps are contiguous, so what the walk reads along a row
+    // or a diagonal sits in one cache line (consecutive stores of a lane fill its 128-byte lines in L2)
+    const size_t t_ss = 4;
+    uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * Tmax) * 256 + (size_t)lane * Tmax * 4 : nullptr;
     auto push = [&](int &pl, int a, int b) {          // pl = 2 * pl + (a < b), per half
         typedef unsigned short u2 __attribute__((ext_vector_type(2)));
         const u2 fifteen = {15, 15};

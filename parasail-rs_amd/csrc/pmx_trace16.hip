@@ -344,17 +344,33 @@ __global__ void pmx_walk16_kernel(const uint8_t *qbuf, const int64_t *qoff, cons
     const uint8_t *q = qbuf + qb, *r = rbuf + rb;
     const unsigned char *sq = w_lds + (qb - qlo), *sr = w_lds + stage + (rb - rlo);
     const long long block = pair / NP; const int slot = (int)(pair % NP);
-    // PACKED: records of 16 bytes per lane and step -- byte b of a record: half (slot & 1) * 8 + row-in-lane / 2, the even row in the
-    // high nibble; Tmax < 0: lane-major (a lane's steps contiguous), else step-major.  Unpacked: R / 8 words per lane and step.
-    const int TmaxA = Tmax < 0 ? -Tmax : Tmax;
-    const uint32_t *tb = tbuf + (size_t)block * TmaxA * (64 * TW);
-    const size_t t_ls = Tmax < 0 ? (size_t)TmaxA * 4 : 4, t_ss = Tmax < 0 ? 4 : 256;
+    // PACKED: records of 16 bytes per lane and step, lane-major (a lane's steps are contiguous): [A rows 0-7][A rows 8-15][B rows 0-7]
+    // [B rows 8-15], byte = a row pair, the even row in the high nibble.  A walk moves along a row or a diagonal, i.e. down one
+    // lane's steps: the lane keeps a window of 8 consecutive records (one 128-byte line of that stream) in LDS and goes back to
+    // memory only when the path leaves it.  Unpacked (first generation): R / 8 words per lane and step, step-major.
+    const uint32_t *tb = tbuf + (size_t)block * Tmax * (64 * TW);
     const int P = top_aligned ? 0 : QP - ql;
+    __shared__ uint4 s_win[PACKED ? 64 * 8 : 1];
+    int w_stream = -1, w_t0 = -1;
     auto ldw = [&](int i, int j) -> uint32_t {         // the trace word holding cell (i, j); 0 outside i >= -1, j >= 0
         if (i < -1 || j < 0) return 0u;
-        const int er = i + P, g = er / R, k = er % R;
-        return PACKED ? tb[(size_t)(j + g) * t_ss + (size_t)((slot >> 1) * G + g) * t_ls + (slot & 1) * 2 + (k / 8)]
-                      : tb[(size_t)(j + g) * (64 * TW) + (slot * G + g) * TW + (k / 8)];
+        const int er = i + P;
+        if (er < 0) return 0u;
+        const int g = er / R, k = er % R;
+        if (!PACKED) return tb[(size_t)(j + g) * (64 * TW) + (slot * G + g) * TW + (k / 8)];
+        const int stream = (slot >> 1) * G + g, t = j + g, t0 = t & ~7;
+        const int lx = threadIdx.x;
+        if (stream != w_stream || t0 != w_t0) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(tb + ((size_t)stream * Tmax + t0) * 4);
+            uint4 v[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) v[x] = src[x];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) s_win[lx * 8 + ((x ^ lx) & 7)] = v[x];
+            w_stream = stream; w_t0 = t0;
+        }
+        const uint32_t *rec4 = reinterpret_cast<const uint32_t *>(&s_win[lx * 8 + (((t & 7) ^ lx) & 7)]);
+        return rec4[(slot & 1) * 2 + (k / 8)];
     };
     auto nibof = [&](uint32_t w, int i) -> unsigned {
         const int k8 = ((i + P) % R) % 8;
@@ -454,18 +470,18 @@ static int launch_trace(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
 // Picks the instantiation; *trace_bytes / *Tmax tell the caller how much trace scratch to provide
 // (call once with tbuf == nullptr to size it).  Returns 1 when the batch is not eligible.
 int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
-                     int *variant, int *Tmax, size_t *trace_bytes)
+                     int *variant, int *Tmax, size_t *trace_bytes, bool packed_ok)
 {
     if (getenv("PMX_NO_FAST_TRACE")) return 1;
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG && mode != PMX_MODE_SW) return 1;
     if (m.msize > PMX_MAX_FAST_MSIZE - 1) return 1;
     if (open < ext || open < 0 || ext < 0 || open > 4096) return 1;
     if (b.max_rlen > 30000 || b.q_shared) return 1;
-    if (!getenv("PMX_TRACE16_GEN1") && pmx_nwsgv_trace_plan(b, m, mode, open, ext, variant, Tmax, trace_bytes) == 0) {
+    if (packed_ok && !getenv("PMX_TRACE16_GEN1") && pmx_nwsgv_trace_plan(b, m, mode, open, ext, variant, Tmax, trace_bytes) == 0) {
         *variant += 10;            // packed traceback of the second-generation nw/sg kernel
         return 0;
     }
-    if (mode == PMX_MODE_SW && pmx_sw16_trace_plan(b, m, open, ext, variant, Tmax, trace_bytes) == 0) {
+    if (packed_ok && mode == PMX_MODE_SW && pmx_sw16_trace_plan(b, m, open, ext, variant, Tmax, trace_bytes) == 0) {
         *variant += 20;            // packed traceback of the local kernel
         return 0;
     }
@@ -495,12 +511,10 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
     const int col_pen_ = sw ? 0 : !(sg_ && (sg_flags & PMX_SG_QB)), row_pen_ = sw ? 0 : !(sg_ && (sg_flags & PMX_SG_DB));
     if (variant >= 10) {
         const int top = variant >= 20 ? 1 : 0;
-        static const bool step_major = [] { const char *e = getenv("PMX_TRACE_LAYOUT"); return e && e[0] == 's'; }();
-        Tmax = step_major ? Tmax : -Tmax;               // sign = layout, for the sweep and for the walk
+        // (Tmax is a multiple of 16 -- the plans round it -- so a walk window never crosses into the next lane's stream)
         int rc = top ? pmx_launch_sw16_trace(variant - 20, b, m, open, ext, d_out, tbuf, Tmax, stream)
                      : pmx_launch_nwsgv_trace(variant - 10, b, m, mode, sg_flags, open, ext, d_out, tbuf, Tmax, stream);
         if (rc) return rc;
-        const int stage = walk_stage_bytes(b);
         hipStream_t wstream = stream;
         if (split && split->walk_stream != stream) {      // the walk runs beside the next chunk's sweep
             hipError_t e1 = hipEventRecord(split->sweep_done, stream);
@@ -510,17 +524,10 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
         }
         const long long ops_base = split ? split->ops_base : 0;
         int32_t *textlen = split ? split->textlen : nullptr;
-#define WALKP(GG) { const int rca = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_walk16_kernel<GG, 16, true>), 128 * 1024); if (rca) return rca; } \
-                  hipLaunchKernelGGL((pmx_walk16_kernel<GG, 16, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 2 * (size_t)stage, wstream, \
-                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, stage, top, stats_out, row_pen_, col_pen_,     \
-                       (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, ops_base, nops, beg, textlen)
-        switch ((variant % 10) & 3) {          // lane-group size: 8, 16, 32, 64 (variants 4..7 are the matrix-lookup kernels)
-        case 0: WALKP(8); break;
-        case 1: WALKP(16); break;
-        case 2: WALKP(32); break;
-        default: WALKP(64); break;
-        }
-#undef WALKP
+        // (Tmax is a multiple of 16 -- the plans round it -- so a walk window never crosses into the next lane's stream)
+        rc = pmx_launch_walkp((variant % 10) & 3, 16, b, m, mode, open, ext, Tmax, top, stats_out, row_pen_, col_pen_,
+                              (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, ops_base, nops, beg, textlen, wstream);
+        if (rc) return rc;
         hipError_t e = hipGetLastError();
         if (e == hipSuccess && split && split->walk_done) e = hipEventRecord(split->walk_done, wstream);
         return e == hipSuccess ? 0 : -(int)e;

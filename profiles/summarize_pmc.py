@@ -6,6 +6,7 @@ from collections import defaultdict
 
 def main(root, needle, out):
     acc = defaultdict(lambda: defaultdict(float))       # counter -> dispatch id -> sum over dimensions
+    kname = None
     for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
@@ -13,9 +14,10 @@ def main(root, needle, out):
                     continue
                 acc[row["Counter_Name"]][(path, row["Dispatch_Id"])] += float(row["Counter_Value"])
     res = {c: {"launches": len(d), "mean_per_launch": sum(d.values()) / len(d)} for c, d in acc.items()}
+    res["kernel"] = needle
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
-    print(json.dumps({c: round(v["mean_per_launch"]) for c, v in res.items()}))
+    print(json.dumps({c: round(v["mean_per_launch"]) for c, v in res.items() if isinstance(v, dict)}))
 
 
 if __name__ == "__main__":
