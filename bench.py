@@ -49,7 +49,8 @@ VALU_MODEL = {
     "pmx_sw16q_kernel": (5.5, 3.0, "sw16q (shared profile): 5.5 VOP3/VOP3P + 3 VOP2 per 128 cells"),
     "pmx_stats16p_kernel": (30.0, 4.0, "stats16p: score arithmetic 7 + nine statistic planes moved by v_bfi_b32 under sign masks"),
     "pmx_stats16c_kernel": (17.0, 4.0, "stats16c: score arithmetic 7 + one combined statistics word per H/E/F moved by v_cndmask"),
-    "pmx_nwsg16v_kernel/packed trace": (12.75, 2.0, "nwsg16v + traceback: 7 score + 4 packed differences + 3.75 bit merges per 128 cells"),
+    "pmx_nwsg16v_kernel/packed trace": (12.25, 3.0, "nwsg16v + traceback: score 4 VOP3 + 3 VOP2, 4 packed differences + 3.5 v_bfi merges + 0.75 v_perm per 128 cells"),
+    "pmx_nwsg16q_kernel/packed trace": (12.1, 3.0, "nwsg16q + traceback: score 4 VOP3 + 3 VOP2, 4 packed differences + 3.5 v_bfi merges + 0.6 v_perm per 128 cells"),
     "pmx_nwsg16v_kernel": (4.0, 3.0, "nwsg16v: 4 VOP3/VOP3P + 3 VOP2 per 128 cells"),
 }
 

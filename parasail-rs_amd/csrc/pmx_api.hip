@@ -989,6 +989,93 @@ static int scratch_reserve(size_t bytes, void **out, int slot = SCR_BOUND)
 static thread_local const char *g_last_kernel = "";
 extern "C" const char *pmx_last_kernel(void) { return g_last_kernel; }
 
+
+// ---- statistics of the profile arm by traceback ------------------------------------------------------------
+// matches / similar / length are properties of the one path the coupled statistics tables follow (same decisions, same
+// tie-breaks as the traceback bits): the shared-profile sweep writes the packed 4-bit records (14.75 instructions per two
+// cells against 34 for the kernel that carries nine statistics planes) and the walk counts along the path.  Chunks bound
+// the trace scratch; the walk of chunk c runs beside the sweep of chunk c + 1 on a second stream.
+struct TraceWs { hipStream_t walk = nullptr; hipEvent_t sweep_done[2] = {nullptr, nullptr}, walk_done[2] = {nullptr, nullptr}; int dev = -1; };
+static thread_local TraceWs g_tws;
+static int trace_ws_init()
+{
+    int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
+    if (g_tws.dev == dev) return 0;
+    if (g_tws.walk) {
+        (void)hipStreamDestroy(g_tws.walk);
+        for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(g_tws.sweep_done[k]); (void)hipEventDestroy(g_tws.walk_done[k]); }
+        g_tws = TraceWs();
+    }
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    HIP_OR_RET(hipStreamCreateWithPriority(&g_tws.walk, hipStreamNonBlocking, prio_hi));
+    for (int k = 0; k < 2; ++k) {
+        HIP_OR_RET(hipEventCreateWithFlags(&g_tws.sweep_done[k], hipEventDisableTiming));
+        HIP_OR_RET(hipEventCreateWithFlags(&g_tws.walk_done[k], hipEventDisableTiming));
+    }
+    g_tws.dev = dev;
+    return 0;
+}
+
+// 0 done (asynchronously on st), 1 not eligible, <0 error
+static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch &b,
+                                 pmx_record_t *d_out, pmx_stats_t *d_stats, hipStream_t st)
+{
+    if (getenv("PMX_NO_STATS_BY_TRACE")) return 1;
+    int variant = 0, Tmax = 0, G = 0, R = 0; size_t tbytes = 0;
+    if (pmx_nwsgq_trace_plan(b, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes, &G, &R) != 0) return 1;
+    if (trace_ws_init()) return -1;
+    const long long NP = 2 * (64 / G) * 4;                     // pairs per workgroup of the sweep
+    double chunk_bytes = 16e9;
+    { size_t fb = 0, tb = 0; if (hipMemGetInfo(&fb, &tb) == hipSuccess && 0.2 * (double)fb < chunk_bytes) chunk_bytes = 0.2 * (double)fb; }
+    if (const char *e = getenv("PMX_STATS_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
+    const double per_pair = (double)tbytes / (double)b.n;
+    long long chunk = (long long)(chunk_bytes / per_pair) / NP * NP;
+    if (chunk < NP) chunk = NP;
+    if (chunk >= b.n) chunk = b.n;
+    else {                                                     // equal shares
+        const long long nch = (b.n + chunk - 1) / chunk;
+        chunk = ((b.n + nch - 1) / nch + NP - 1) / NP * NP;
+    }
+    PmxBatch bc = b; bc.n = chunk;
+    size_t cbytes = 0;
+    (void)pmx_nwsgq_trace_plan(bc, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &cbytes, &G, &R);
+    cbytes = (cbytes + 255) & ~(size_t)255;
+    const bool two = chunk < b.n;
+    uint32_t *tbuf = nullptr;
+    if (scratch_reserve(cbytes * (two ? 2 : 1), (void **)&tbuf, SCR_TRACE)) return -1;
+    const bool sg = cfg->mode == PMX_MODE_SG;
+    const int col_pen = !(sg && (cfg->sg_flags & PMX_SG_QB)), row_pen = !(sg && (cfg->sg_flags & PMX_SG_DB));
+    const int gsel = G == 16 ? 1 : G == 32 ? 2 : 3;
+    int idx = 0;
+    for (long long c0 = 0; c0 < b.n; c0 += chunk, ++idx) {
+        PmxBatch bk = b;
+        bk.n = (b.n - c0 < chunk) ? b.n - c0 : chunk;
+        pmx_record_t *out_k = d_out; pmx_stats_t *st_k = d_stats;
+        if (b.perm) bk.perm = b.perm + c0;                    // positions c0 .. of the processing order; records stay indexed by pair
+        else { bk.roff = b.roff + c0; out_k = d_out + c0; st_k = d_stats + c0; }
+        uint32_t *tb = (uint32_t *)((unsigned char *)tbuf + (two ? (size_t)(idx & 1) * cbytes : 0));
+        if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(st, g_tws.walk_done[idx & 1], 0));
+        int rc = pmx_launch_nwsgq_trace(variant, bk, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, out_k, tb, Tmax, st);
+        if (rc) { set_err("shared-profile traceback sweep failed (%d)", rc); return rc < 0 ? rc : -1; }
+        hipStream_t ws = st;
+        if (two) {
+            HIP_OR_RET(hipEventRecord(g_tws.sweep_done[idx & 1], st));
+            HIP_OR_RET(hipStreamWaitEvent(g_tws.walk, g_tws.sweep_done[idx & 1], 0));
+            ws = g_tws.walk;
+        }
+        rc = pmx_launch_walkp(gsel, R, bk, dm.d, cfg->mode, cfg->open, cfg->extend, Tmax, 0, st_k, row_pen, col_pen,
+                              tb, out_k, nullptr, nullptr, 0, nullptr, nullptr, nullptr, ws);
+        if (rc) { set_err("statistics walk failed (%d)", rc); return rc < 0 ? rc : -1; }
+        if (two) HIP_OR_RET(hipEventRecord(g_tws.walk_done[idx & 1], ws));
+    }
+    if (two) HIP_OR_RET(hipStreamWaitEvent(st, g_tws.walk_done[(idx - 1) & 1], 0));
+    static thread_local char name[96];
+    snprintf(name, sizeof name, "pmx_nwsg16q_kernel<%d,%d>/shared profile/packed trace + pmx_walkp_kernel/stats", G, R);
+    g_last_kernel = name;
+    return 0;
+}
+
 // Device-resident batch.  q_shared > 0: every pair uses the one query d_qbuf[0..q_shared) (profile arm).
 static int run_batch_device(const pmx_config_t *cfg, int64_t n,
                             const uint8_t *d_qbuf, const int64_t *d_qoff, int q_shared,
@@ -1061,6 +1148,13 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
     // statistics: (0) small alphabets in full batches: counts along the packed traceback; (1) the packed statistics kernel
     // (shared profile, or per-pair over a large alphabet, no free end); (2) large alphabets with short references: traceback
     // again; (3) the unpacked statistics kernel
+    if (q_shared && want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&
+        (cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && (n >= 512 || getenv("PMX_STATS_BY_TRACE"))) {
+        // profile arm with statistics (BASELINE config 3): traceback sweep + counting walk
+        const int rc = stats_by_trace_shared(cfg, dm, b, d_out, d_stats_out, st);
+        if (rc < 0) return rc;
+        if (rc == 0) return 0;
+    }
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
             if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {

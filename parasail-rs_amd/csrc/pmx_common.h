@@ -56,6 +56,12 @@ int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
 int pmx_launch_nwsgv_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                            pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream);
 
+// Traceback with a shared query (pmx_nwsg16q_kernel<..., TR>): statistics of the profile arm are counted along the path.
+int pmx_nwsgq_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
+                         int *variant, int *Tmax, size_t *trace_bytes, int *G_out, int *R_out);
+int pmx_launch_nwsgq_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
+                           pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream);
+
 // Shared-query variant of the local kernel (pmx_sw16q.hip); called by pmx_launch_sw16 once the skewed byte-profile
 // variant's conditions hold.  0 launched, 1 not eligible, <0 HIP error.
 int pmx_launch_sw16q(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,

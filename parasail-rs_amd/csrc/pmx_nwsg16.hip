@@ -735,7 +735,10 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 // every pair) and reference symbols fetched from HBM two steps ahead instead of being staged in LDS -- what
 // pmx_sw16q.hip does for local alignment.  A protein profile plus four staged 5-kaa references cost 58 KB per
 // wave otherwise.
-template <int G, int R, int WAVES>
+// TR: the same sweep also writes the packed traceback records (R / 2 bytes per pair, lane and step; see pmx_walkp.hip) with the
+// one-instruction decision merge of pmx_nwsg16v_kernel's TRB form -- what BASELINE config 3 (statistics of a reused profile
+// against long references) runs on: the statistics are counted along the path afterwards.
+template <int G, int R, int WAVES, bool TR = false>
 __global__ __launch_bounds__(64 * WAVES)
 void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
                         const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
@@ -743,8 +746,10 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
                         int msize, int open, int ext,
                         int col_pen, int row_pen, int s1_end, int s2_end, int nb,
                         const unsigned *__restrict__ perm,
-                        pmx_record_t *__restrict__ out)
+                        pmx_record_t *__restrict__ out, uint32_t *__restrict__ tbuf = nullptr, int Tmax = 0)
 {
+    static_assert(!TR || R == 10 || R == 16, "trace record layouts");
+    constexpr int TD = (R + 3) / 4;               // dwords per trace record (R / 2 bytes per pair, two pairs)
     constexpr int RS = (R + 3) / 4 * 4;
     constexpr int QP = G * R;
     constexpr int QPS = G * RS;
@@ -762,6 +767,10 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
     int16_t *mat = reinterpret_cast<int16_t *>(lds + ((MS1 * QPS + 7) & ~7));
     unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
     long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));   // per pair: r offset, rlen, pair index
+    // TR: eight steps of every lane's trace records are gathered in LDS and leave as one contiguous piece of the lane's stream
+    // (96 or 128 bytes: whole 32-byte sectors; single 12/16-byte stores of thousands of resident lanes overflow the L2's write combining)
+    constexpr int TSTR = 8 * TD + 1;              // dwords per lane (odd: the lanes' stores of a step fall into different banks)
+    uint32_t *tstage = reinterpret_cast<uint32_t *>(ptab + 3 * NP) + (size_t)(wave * 64 + lane) * TSTR;
 
     const long long pair0 = (long long)blockIdx.x * NP;
     for (int i = tid; i < msize * msize; i += NT) mat[i] = gmat[i];
@@ -831,10 +840,12 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
 #pragma unroll
         for (int x = 0; x < RS / 4; ++x) { w[bsel][0][x] = a[x]; w[bsel][1][x] = b[x]; }
     };
-    auto step = [&](int bsel) {
+    uint32_t *tw = TR ? tbuf + (((size_t)blockIdx.x * WAVES + wave) * 64 + lane) * (size_t)Tmax * TD : nullptr;
+    auto step = [&](int bsel, int t) {
         const int Hin = n_shift_up<G>(Hout, topX, g);
         int F = n_shift_up<G>(Fout, topX, g);
         int Tpre[R];
+        int tacc = 0, ty[TR ? R / 2 : 1];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int s = __builtin_amdgcn_perm(w[bsel][1][k / 4], w[bsel][0][k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16));
@@ -846,9 +857,40 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
             const int Fe = F - vExt;
             const int H = I32(n_max3f(PK(Tpre[k]), PK(E[k]), PK(Fe)));
             const int Xn = H - vC;
+            if (TR) {     // ND, NDL, EO, FO: the sign of each difference, inserted at its bit of the row pair's byte (see pmx_nwsg16v_kernel)
+                const int dND = I32(PK(Tpre[k]) - PK(H)), dNDL = I32(PK(Fe) - PK(H));
+                const int dEO = I32(PK(E[k]) - PK(Xn)), dFO = I32(PK(Fe) - PK(Xn));
+                if ((k & 1) == 0) {
+                    tacc = dND;
+                    tacc = s_bfi(0x40004000, dNDL, tacc);
+                    tacc = s_bfi(0x20002000, dEO, tacc);
+                    tacc = s_bfi(0x10001000, dFO, tacc);
+                } else {
+                    tacc = s_bfi(0x08000800, dND, tacc);
+                    tacc = s_bfi(0x04000400, dNDL, tacc);
+                    tacc = s_bfi(0x02000200, dEO, tacc);
+                    tacc = s_bfi(0x01000100, dFO, tacc);
+                    ty[k / 2] = tacc;                      // byte 1: pair A's rows k-1, k; byte 3: pair B's
+                }
+            }
             E[k] = I32(n_max3f(PK(E[k]), PK(Xn), PK(Xn)));
             F = I32(n_max3f(PK(Fe), PK(Xn), PK(Xn)));
             X[k] = Xn;
+        }
+        if (TR) {
+            // record: [A bytes 0 .. R/2-1][B bytes 0 .. R/2-1][pad]; u = [A_y A_y+1 B_y B_y+1] of two row pairs
+            const int u01 = __builtin_amdgcn_perm(ty[0], ty[1], 0x03070105), u23 = __builtin_amdgcn_perm(ty[2], ty[3], 0x03070105);
+            const int a0 = __builtin_amdgcn_perm(u01, u23, 0x01000504), b0 = __builtin_amdgcn_perm(u01, u23, 0x03020706);
+            uint32_t *dst = tstage + (t & 7) * TD;
+            if (R == 16) {
+                const int u45 = __builtin_amdgcn_perm(ty[4], ty[R == 16 ? 5 : 0], 0x03070105), u67 = __builtin_amdgcn_perm(ty[R == 16 ? 6 : 0], ty[R == 16 ? 7 : 0], 0x03070105);
+                dst[0] = (uint32_t)a0; dst[1] = (uint32_t)__builtin_amdgcn_perm(u45, u67, 0x01000504);
+                dst[2] = (uint32_t)b0; dst[TD - 1] = (uint32_t)__builtin_amdgcn_perm(u45, u67, 0x03020706);
+            } else {
+                dst[0] = (uint32_t)a0;                                                    // A0 A1 A2 A3
+                dst[1] = (uint32_t)__builtin_amdgcn_perm(ty[4], b0, 0x02010005);          // A4 B0 B1 B2
+                dst[2] = (uint32_t)__builtin_amdgcn_perm(ty[4], b0, 0x0C0C0703);          // B3 B4 0 0
+            }
         }
         diag0 = Hin;
         Hout = X[R - 1];
@@ -899,14 +941,22 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
         nsA = sym_of(m2a); nsB = sym_of(m2b);
         fetch(t + 4, m2a, m2b);
         __builtin_amdgcn_sched_barrier(0);
-        step(0);
+        step(0, t);
         __builtin_amdgcn_sched_barrier(0);
         load_scores(0, nsA, nsB);
         nsA = sym_of(m3a); nsB = sym_of(m3b);
         fetch(t + 5, m3a, m3b);
         __builtin_amdgcn_sched_barrier(0);
-        step(1);
+        step(1, t + 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (TR && ((t & 6) == 6 || t + 2 >= T)) {          // eight steps gathered (or the sweep ends): one piece of the lane's stream
+            uint4 *gdst = reinterpret_cast<uint4 *>(tw + (size_t)(t & ~7) * TD);
+#pragma unroll
+            for (int x = 0; x < 2 * TD; ++x) {
+                uint4 v; v.x = tstage[4 * x]; v.y = tstage[4 * x + 1]; v.z = tstage[4 * x + 2]; v.w = tstage[4 * x + 3];
+                gdst[x] = v;
+            }
+        }
     }
 
     unsigned keyA = ((unsigned)(I32(bestcol) & 0xFFFF) << 16) | (0xFFFFu - (unsigned)(bestcoli & 0xFFFF));
@@ -1224,24 +1274,64 @@ static int launch_nwsgm(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     return e == hipSuccess ? 0 : -(int)e;
 }
 
-template <int G, int R>
+template <int G, int R, bool TR = false>
 static int launch_nwsgq(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
-                        pmx_record_t *d_out, hipStream_t stream)
+                        pmx_record_t *d_out, hipStream_t stream, uint32_t *tbuf = nullptr, int Tmax = 0)
 {
     constexpr int RS = (R + 3) / 4 * 4, WAVES = 4, NP = 2 * (64 / G) * WAVES;
-    const size_t lds = (size_t)(m.msize + 1) * G * RS + 8 + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 24;
+    const size_t lds = (size_t)(m.msize + 1) * G * RS + 8 + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 24 +
+                       (TR ? (size_t)WAVES * 64 * (8 * ((R + 3) / 4) + 1) * 4 : 0);
     if (lds > 160 * 1024) return 1;
-    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16q_kernel<G, R, WAVES>)); if (rc) return rc; }
+    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16q_kernel<G, R, WAVES, TR>)); if (rc) return rc; }
     const bool sg = mode == PMX_MODE_SG;
     const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
-    hipLaunchKernelGGL((pmx_nwsg16q_kernel<G, R, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream,
+    hipLaunchKernelGGL((pmx_nwsg16q_kernel<G, R, WAVES, TR>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream,
                        b.qbuf, b.q_shared, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper, m.msize, open, ext,
-                       col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out);
+                       col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
+}
+
+// Traceback with a shared query (profile arm): shapes <16,10> <16,16> <32,10> <32,16> <64,16>, one virtual row at least on top
+// (the walk needs row -1), bounded differences for the one-instruction decision merge.  *variant = 30 + shape index.
+static const int kQShapeG[5] = {16, 16, 32, 32, 64}, kQShapeR[5] = {10, 16, 10, 16, 16};
+int pmx_nwsgq_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
+                         int *variant, int *Tmax, size_t *trace_bytes, int *G_out, int *R_out)
+{
+    if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
+    if (!b.q_shared || !pmx_nwsgv_bias(b, m, open, ext)) return 1;
+    if ((m.max > 0 ? m.max : 0) + 2 * open > 250) return 1;
+    for (int v = 0; v < 5; ++v) {
+        const int G = kQShapeG[v], R = kQShapeR[v];
+        if (b.q_shared > G * R - 1) continue;
+        const size_t lds = (size_t)(m.msize + 1) * G * ((R + 3) / 4 * 4) + 8 + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)(2 * (64 / G) * 4) * 24 +
+                           (size_t)4 * 64 * (8 * ((R + 3) / 4) + 1) * 4;
+        if (lds > 160 * 1024) continue;
+        const long long NP = 2 * (64 / G) * 4;
+        *variant = 30 + v; *G_out = G; *R_out = R;
+        *Tmax = (b.max_rlen + G - 1 + 1 + 15) & ~15;
+        *trace_bytes = (size_t)((b.n + NP - 1) / NP) * 4 * (size_t)*Tmax * 64 * (size_t)((R + 3) / 4) * 4;
+        return 0;
+    }
+    return 1;
+}
+
+int pmx_launch_nwsgq_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
+                           pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream)
+{
+    const int nb = pmx_nwsgv_bias(b, m, open, ext);
+    if (!nb) return 1;
+    switch (variant - 30) {
+    case 0: return launch_nwsgq<16, 10, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 1: return launch_nwsgq<16, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 2: return launch_nwsgq<32, 10, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 3: return launch_nwsgq<32, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 4: return launch_nwsgq<64, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    }
+    return 1;
 }
 
 // ------------------------------------------------------------------------ host side ----

@@ -201,6 +201,7 @@ int pmx_launch_walkp(int gsel, int R, const PmxBatch &b, const PmxDevMatrix &m, 
         }
     } else if (R == 10) {
         switch (gsel) {
+        case 1: WALKP(16, 10); break;
         case 2: WALKP(32, 10); break;
         default: return 1;
         }

@@ -35,7 +35,7 @@ def test_cfg3_shared_profile_nw_stats_full_shape(pkg, orc):
     assert al.fn_name == wl.CFG3["name"]
     rec, st = al.align_batch_packed(None, None, rbuf, roff)
     kernel = pkg.lib.pmx_last_kernel().decode()
-    assert "stats16p" in kernel, kernel
+    assert "nwsg16q" in kernel and "packed trace" in kernel and "stats" in kernel, kernel     # traceback sweep + counting walk
     rlen = (roff[1:] - roff[:-1]).astype(np.int64)
     # every pair: global ends, no saturation at 16 bits, statistics consistent with each other and with the lengths
     assert (rec["flags"] == 0).all()
@@ -57,6 +57,19 @@ def test_cfg3_shared_profile_nw_stats_full_shape(pkg, orc):
                     st["matches"][idx], st["similar"][idx], st["length"][idx], rec["flags"][idx] & 1], axis=1)
     assert (got == want).all(), (got[(got != want).any(axis=1)][:5], want[(got != want).any(axis=1)][:5])
     assert rec["score"].min() < -4000          # the global score of a 300-aa query against 5 kaa: deep in the negative range
+    # the kernel that carries the statistics with H, E and F (the path for matrices outside the traceback sweep's window) agrees
+    # on every pair of the first 2 000 references, as does the traceback route forced into many small chunks
+    m = 2000
+    import os as _os
+    for env, val in (("PMX_NO_STATS_BY_TRACE", "1"), ("PMX_STATS_CHUNK_BYTES", "300e6")):
+        _os.environ[env] = val
+        try:
+            rec2, st2 = al.align_batch_packed(None, None, rbuf[:roff[m]], roff[:m + 1])
+            k2 = pkg.lib.pmx_last_kernel().decode()
+        finally:
+            del _os.environ[env]
+        assert ("stats16p" in k2) == (env == "PMX_NO_STATS_BY_TRACE"), k2
+        assert (rec2 == rec[:m]).all() and (st2 == st[:m]).all(), env
 
 
 def test_cfg3_one_off_form_matrix_lookup(pkg, orc):
