@@ -500,6 +500,9 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
     DevBuf<int32_t> dbound, dtab[4], drow[4], dcol[4]; DevBuf<int8_t> dtrace;
     dq.alloc(s1Len); dr.alloc(s2Len); doff.alloc(4); drec.alloc(1); dst.alloc(1);
     dbound.alloc((size_t)8 * s2Len);
+    DevBuf<uint8_t> drs;                                     // references beyond the LDS: mapped copy in HBM
+    const bool rs_fits = pmx_general_lds_fits(matrix->length, matrix->size, s2Len);
+    if (!rs_fits) drs.alloc((size_t)s2Len + 32);
     const int64_t offs[4] = {0, s1Len, 0, s2Len};
     HIP_OR_DIE(hipMemcpy(dq.p, s1, s1Len, hipMemcpyHostToDevice));
     HIP_OR_DIE(hipMemcpy(dr.p, s2, s2Len, hipMemcpyHostToDevice));
@@ -512,6 +515,7 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
     a.mode = sp.mode; a.sg_flags = sp.sg_flags; a.open = open; a.ext = gap; a.band = sp.band;
     a.bits = sp.width;
     a.bound = dbound.p; a.bound_stride = (long long)8 * s2Len;
+    if (!rs_fits) { a.rs_scratch = drs.p; a.rs_stride = (long long)s2Len + 32; }
     a.rec = drec.p; a.stats = dst.p;
     const int ntab = sp.stats ? 4 : 1;
     if (sp.table) for (int k = 0; k < ntab; ++k) dtab[k].alloc(cells);
@@ -631,8 +635,9 @@ struct parasail_profile {
     char *s1; int s1Len;
     const parasail_matrix_t *matrix;
     int stats; int width;
-    // device copy of the query for the batch entries (uploaded on first use, per device)
-    mutable uint8_t *d_s1; mutable int d_dev; mutable std::mutex *mx;
+    // device copies of the query for the batch entries: one per device, uploaded on first use there, freed with the profile
+    // (a Profile is Send + Sync in the reference, src/profile/mod.rs:392-395: threads driving different GPUs may share one)
+    mutable std::vector<std::pair<int, uint8_t *>> *d_copies; mutable std::mutex *mx;
 };
 
 static parasail_profile_t *profile_new(const char *s1, int s1Len, const parasail_matrix_t *matrix, int stats, int width)
@@ -644,14 +649,16 @@ static parasail_profile_t *profile_new(const char *s1, int s1Len, const parasail
     if (!p->s1) { free(p); return nullptr; }
     memcpy(p->s1, s1, (size_t)s1Len); p->s1[s1Len] = 0;
     p->s1Len = s1Len; p->matrix = matrix; p->stats = stats; p->width = width;
-    p->d_s1 = nullptr; p->d_dev = -1; p->mx = new std::mutex;
+    p->d_copies = new std::vector<std::pair<int, uint8_t *>>; p->mx = new std::mutex;
     return p;
 }
 extern "C" void parasail_profile_free(parasail_profile_t *p)
 {
     if (!p) return;
-    if (p->d_s1) (void)hipFree(p->d_s1);
-    delete p->mx;
+    int cur = 0; const bool have_dev = hipGetDevice(&cur) == hipSuccess;
+    for (auto &c : *p->d_copies) { if (have_dev) (void)hipSetDevice(c.first); (void)hipFree(c.second); }
+    if (have_dev && !p->d_copies->empty()) (void)hipSetDevice(cur);
+    delete p->d_copies; delete p->mx;
     free(p->s1); free(p);
 }
 // the query maps to a column beyond the first four of the matrix alphabet somewhere (the perm-table kernel cannot express that)
@@ -666,14 +673,13 @@ static int profile_device_query(const parasail_profile_t *p, const uint8_t **out
 {
     int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(*p->mx);
-    if (!p->d_s1 || p->d_dev != dev) {
-        if (p->d_s1) (void)hipFree(p->d_s1);
-        p->d_s1 = nullptr;
-        HIP_OR_RET(hipMalloc(&p->d_s1, (size_t)p->s1Len));
-        HIP_OR_RET(hipMemcpy(p->d_s1, p->s1, (size_t)p->s1Len, hipMemcpyHostToDevice));
-        p->d_dev = dev;
-    }
-    *out = p->d_s1;
+    for (auto &c : *p->d_copies) if (c.first == dev) { *out = c.second; return 0; }
+    uint8_t *d = nullptr;
+    HIP_OR_RET(hipMalloc(&d, (size_t)p->s1Len + 16));
+    hipError_t e = hipMemcpy(d, p->s1, (size_t)p->s1Len, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); set_err("hipMemcpy: %s", hipGetErrorString(e)); return -(int)e; }
+    p->d_copies->emplace_back(dev, d);
+    *out = d;
     return 0;
 }
 
@@ -1122,22 +1128,27 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
             if (bound_score <= 27000) return 0;
             const int mask = PMX_FLAG_RERUN | ((cfg->width == 16 || cfg->width == 8) ? 0 : PMX_FLAG_SATURATED);
             DevBuf<int64_t> list; DevBuf<int> cnt;
-            list.alloc((size_t)n); cnt.alloc(1);
+            if (list.try_alloc((size_t)n) || cnt.try_alloc(1)) { set_err("out of device memory (promotion list)"); return -2; }
             int rc2 = pmx_launch_collect_saturated(d_out, n, list.p, cnt.p, mask, st);
             if (rc2) { set_err("collect kernel failed (%d)", rc2); return rc2; }
             int count = 0;
             HIP_OR_RET(hipMemcpyAsync(&count, cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_OR_RET(hipStreamSynchronize(st));
             if (count == 0) return 0;
-            DevBuf<int32_t> bnd;
+            DevBuf<int32_t> bnd; DevBuf<uint8_t> rsb;
             const size_t stride2 = (size_t)8 * max_rlen;
-            bnd.alloc((size_t)count * stride2);
+            const bool fits2 = pmx_general_lds_fits(dm.d.msize, dm.d.msize, max_rlen);
+            const size_t rs2 = fits2 ? 0 : (((size_t)max_rlen + 8 + 15) & ~(size_t)15);
+            if (bnd.try_alloc((size_t)count * stride2) || (!fits2 && rsb.try_alloc((size_t)count * rs2))) {
+                set_err("out of device memory (promotion pass of %d pairs)", count); return -2;
+            }
             PmxGeneralArgs a; memset(&a, 0, sizeof a);
             a.qbuf = d_qbuf; a.qoff = q_shared ? nullptr : d_qoff; a.shared_qlen = q_shared;
             a.rbuf = d_rbuf; a.roff = d_roff; a.n = count; a.index = list.p; a.max_rlen = max_rlen;
             a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
             a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
             a.bits = cfg->width == 16 ? 16 : cfg->width == 8 ? 8 : 32; a.bound = bnd.p; a.bound_stride = (long long)stride2; a.rec = d_out;
+            if (!fits2) { a.rs_scratch = rsb.p; a.rs_stride = (long long)rs2; }
             rc2 = pmx_launch_general(a, false, st);
             if (rc2) { set_err("promotion launch failed (%d)", rc2); return rc2 < 0 ? rc2 : -1; }
             HIP_OR_RET(hipStreamSynchronize(st));      // scratch is released on return
@@ -1212,22 +1223,56 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         if (rc == 0) return 0;     // the host-side range proof makes overflow impossible: no promotion pass
     }
     if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
-    void *bound = nullptr;
+    // General kernel (one wave per pair).  Its scratch -- the boundary row between 64-row bands, 8 ints per reference column, and
+    // for references beyond the LDS a mapped copy in HBM -- only has to cover the pairs of one launch: chunks of at most ~2 GB.
     const size_t stride = (size_t)8 * max_rlen;
-    if (scratch_reserve((size_t)n * stride * sizeof(int32_t), &bound)) return -1;
-    PmxGeneralArgs a; memset(&a, 0, sizeof a);
-    a.qbuf = d_qbuf; a.qoff = q_shared ? nullptr : d_qoff; a.shared_qlen = q_shared;
-    a.rbuf = d_rbuf; a.roff = d_roff; a.n = n; a.max_rlen = max_rlen;
-    a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize; a.pssm = 0;
-    a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
-    a.bits = cfg->width;
-    a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
-    a.rec = d_out; a.stats = d_stats_out;
-    const int rc = pmx_launch_general(a, (want & PMX_WANT_STATS) != 0, st);
-    if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    const bool fits = pmx_general_lds_fits(dm.d.msize, dm.d.msize, max_rlen);
+    const size_t rs_stride = fits ? 0 : (((size_t)max_rlen + 8 + 15) & ~(size_t)15);
+    const size_t per_pair = stride * sizeof(int32_t) + rs_stride;
+    int64_t chunk = (int64_t)(2e9 / (double)per_pair);
+    if (chunk < 1) chunk = 1;
+    if (chunk > n) chunk = n;
+    void *bound = nullptr;
+    if (scratch_reserve((size_t)chunk * per_pair, &bound)) return -1;
+    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+        const int64_t m = (n - c0 < chunk) ? n - c0 : chunk;
+        PmxGeneralArgs a; memset(&a, 0, sizeof a);
+        a.qbuf = d_qbuf; a.qoff = q_shared ? nullptr : d_qoff + c0; a.shared_qlen = q_shared;
+        a.rbuf = d_rbuf; a.roff = d_roff + c0; a.n = m; a.max_rlen = max_rlen;
+        a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize; a.pssm = 0;
+        a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
+        a.bits = cfg->width;
+        a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
+        if (!fits) { a.rs_scratch = (uint8_t *)bound + (size_t)chunk * stride * sizeof(int32_t); a.rs_stride = (long long)rs_stride; }
+        a.rec = d_out + c0; a.stats = d_stats_out ? d_stats_out + c0 : nullptr;
+        const int rc = pmx_launch_general(a, (want & PMX_WANT_STATS) != 0, st);
+        if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    }
     g_last_kernel = "pmx_general_kernel";
     return 0;
 }
+
+// The device entries keep internal scratch (length-sort permutation, retry list, trace records, op slots) per HOST THREAD.  A thread
+// that queues its next call on ANOTHER stream would let that call overwrite scratch the previous call's kernels may still read:
+// every device entry therefore ends by recording an event on its stream, and a call that arrives on a different stream first makes
+// its stream wait for that event.  Calls on one stream cost nothing extra; calls from different threads never share scratch.
+struct StreamGuard {
+    static thread_local hipEvent_t ev; static thread_local hipStream_t last; static thread_local int dev; static thread_local bool armed;
+    hipStream_t st; bool ok;
+    explicit StreamGuard(void *stream) : st((hipStream_t)stream), ok(true)
+    {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) { ok = false; return; }
+        if (dev != d) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; armed = false; dev = d; }
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ok = false; return; }
+        if (armed && last != st && hipStreamWaitEvent(st, ev, 0) != hipSuccess) ok = false;
+    }
+    ~StreamGuard() { if (ok && ev && hipEventRecord(ev, st) == hipSuccess) { last = st; armed = true; } }
+};
+thread_local hipEvent_t StreamGuard::ev = nullptr;
+thread_local hipStream_t StreamGuard::last = nullptr;
+thread_local int StreamGuard::dev = -1;
+thread_local bool StreamGuard::armed = false;
 
 extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
                                       const uint8_t *d_qbuf, const int64_t *d_qoff,
@@ -1235,6 +1280,8 @@ extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
                                       int32_t max_qlen, int32_t max_rlen,
                                       pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream)
 {
+    StreamGuard guard(stream);
+    if (!guard.ok) { set_err("stream guard failed"); return -1; }
     return run_batch_device(cfg, n, d_qbuf, d_qoff, 0, d_rbuf, d_roff, max_qlen, max_rlen, d_out, d_stats_out, stream);
 }
 
@@ -1343,7 +1390,7 @@ extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_p
     DevBuf<uint8_t> dr; DevBuf<int64_t> dro; DevBuf<pmx_record_t> drec; DevBuf<pmx_stats_t> dst;
     struct { const uint8_t *p; } dq;
     if (profile_device_query(profile, &dq.p)) return -1;
-    dr.alloc(rbytes); dro.alloc(n + 1); drec.alloc(n); if (stats) dst.alloc(n);
+    if (dr.try_alloc(rbytes) || dro.try_alloc(n + 1) || drec.try_alloc(n) || (stats && dst.try_alloc(n))) { set_err("out of device memory"); return -2; }
     HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
     HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     const int rc = run_batch_device(cfg, n, dq.p, nullptr, profile->s1Len, dr.p, dro.p, profile->s1Len, mr,
@@ -1365,6 +1412,8 @@ extern "C" int pmx_align_profile_batch_device(const pmx_config_t *cfg, const par
     if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
     const uint8_t *dq = nullptr;
     if (profile_device_query(profile, &dq)) return -1;
+    StreamGuard guard(stream);
+    if (!guard.ok) { set_err("stream guard failed"); return -1; }
     return run_batch_device(cfg, n, dq, nullptr, profile->s1Len, d_rbuf, d_roff, profile->s1Len, max_rlen,
                             d_out, d_stats_out, stream, profile_has_wildcard(profile));
 }
@@ -1467,6 +1516,8 @@ extern "C" int pmx_align_batch_cigar_device(const pmx_config_t *cfg, int64_t n,
     if (max_qlen <= 0 || max_rlen <= 0) { set_err("max_qlen / max_rlen must be positive"); return -1; }
     DevMat dm;
     if (get_devmat(cfg->matrix, &dm)) return -1;
+    StreamGuard guard(stream);
+    if (!guard.ok) { set_err("stream guard failed"); return -1; }
     const int rc = cigar_device_run(cfg, dm, n, d_qbuf, d_qoff, d_rbuf, d_roff, max_qlen, max_rlen, 0, d_out,
                                     d_cigar_text, cigar_capacity, d_cigar_off, (hipStream_t)stream);
     if (rc == 1) set_err("this configuration has no device-resident CIGAR path (width 8, PSSM, open < extend, a matrix whose score + open "
@@ -1514,8 +1565,8 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
     for (int64_t k = 0; k < n; ++k) ops_off[k + 1] = ops_off[k] + (qoff[k + 1] - qoff[k]) + (roff[k + 1] - roff[k]) + 1;
     const size_t qbytes = (size_t)qoff[n], rbytes = (size_t)roff[n];
     DevBuf<uint8_t> dq, dr; DevBuf<int64_t> dqo, dro, doo; DevBuf<pmx_record_t> drec; DevBuf<int32_t> dnops, dbeg;
-    dq.alloc(qbytes); dr.alloc(rbytes); dqo.alloc(n + 1); dro.alloc(n + 1); doo.alloc(n + 1);
-    drec.alloc(n); dnops.alloc(n); dbeg.alloc(2 * n);
+    if (dq.try_alloc(qbytes) || dr.try_alloc(rbytes) || dqo.try_alloc(n + 1) || dro.try_alloc(n + 1) || doo.try_alloc(n + 1) ||
+        drec.try_alloc(n) || dnops.try_alloc(n) || dbeg.try_alloc(2 * n)) { set_err("out of device memory"); return -2; }
     uint32_t *dops = nullptr;
     if (scratch_reserve((size_t)ops_off[n] * sizeof(uint32_t), (void **)&dops, SCR_OPS)) return -1;
     tm.done("host prep + device alloc");
@@ -1541,13 +1592,17 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
         std::vector<int64_t> tab_off(n + 1);
         tab_off[0] = 0;
         for (int64_t k = 0; k < n; ++k) tab_off[k + 1] = tab_off[k] + (qoff[k + 1] - qoff[k]) * (roff[k + 1] - roff[k]);
-        DevBuf<int64_t> dto; dto.alloc(n + 1);
+        DevBuf<int64_t> dto;
+        if (dto.try_alloc(n + 1)) { set_err("out of device memory"); return -2; }
         HIP_OR_RET(hipMemcpy(dto.p, tab_off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
         int8_t *dtrace = nullptr; void *bound = nullptr;
         if (scratch_reserve((size_t)tab_off[n], (void **)&dtrace, SCR_TRACE)) return -1;
         const size_t stride = (size_t)8 * mr;
-        if (scratch_reserve((size_t)n * stride * sizeof(int32_t), &bound)) return -1;
+        const bool fits = pmx_general_lds_fits(dm.d.msize, dm.d.msize, mr);
+        const size_t rs_stride = fits ? 0 : (((size_t)mr + 8 + 15) & ~(size_t)15);
+        if (scratch_reserve((size_t)n * (stride * sizeof(int32_t) + rs_stride), &bound)) return -1;
         PmxGeneralArgs a; memset(&a, 0, sizeof a);
+        if (!fits) { a.rs_scratch = (uint8_t *)bound + (size_t)n * stride * sizeof(int32_t); a.rs_stride = (long long)rs_stride; }
         a.qbuf = dq.p; a.qoff = dqo.p; a.rbuf = dr.p; a.roff = dro.p; a.n = n; a.max_rlen = mr;
         a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
         a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
@@ -1569,7 +1624,8 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
     // The CIGAR text is rendered on the device: text lengths come back (4 bytes per pair), the host turns them
     // into offsets, the text itself is written there and copied back in one piece.
     HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
-    DevBuf<int32_t> dtl; dtl.alloc(n);
+    DevBuf<int32_t> dtl;
+    if (dtl.try_alloc(n)) { set_err("out of device memory"); return -2; }
     rc = pmx_launch_cigar_textlen(dops, doo.p, dnops.p, dtl.p, n, nullptr);
     if (rc) { set_err("cigar length kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
     std::vector<int32_t> tl(n);
@@ -1578,7 +1634,7 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
     toff[0] = 0;
     for (int64_t k = 0; k < n; ++k) toff[k + 1] = toff[k] + tl[k];
     DevBuf<int64_t> dtoff; DevBuf<char> dtext;
-    dtoff.alloc(n + 1); dtext.alloc((size_t)toff[n] + 1);
+    if (dtoff.try_alloc(n + 1) || dtext.try_alloc((size_t)toff[n] + 1)) { set_err("out of device memory"); return -2; }
     HIP_OR_RET(hipMemcpy(dtoff.p, toff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     rc = pmx_launch_cigar_render(dops, doo.p, dnops.p, dtoff.p, dtext.p, n, nullptr);
     if (rc) { set_err("cigar render kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }

@@ -126,6 +126,8 @@ struct PmxGeneralArgs {
     int bits;                 // 0/32/64: no range check; 8 or 16: report saturation of that range
     // per-pair scratch: boundary row between 64-row bands, 8 ints per reference column
     int32_t *bound; long long bound_stride;       // ints per pair
+    // optional per-block scratch (max_rlen + 8 bytes each) for references that do not fit the LDS; see pmx_general_lds_fits()
+    uint8_t *rs_scratch; long long rs_stride;
     // outputs (device); any may be null
     pmx_record_t *rec; pmx_stats_t *stats;
     // table-like outputs: cell offset of pair k is tab_off[k] (nullptr -> pair 0 at 0, n must be 1)
@@ -138,6 +140,11 @@ struct PmxGeneralArgs {
     int32_t *score_col, *matches_col, *similar_col, *length_col;
 };
 int pmx_launch_general(const PmxGeneralArgs &a, bool want_stats, hipStream_t stream);
+// true if the general kernel can keep a reference of max_rlen symbols (and the matrix) in the LDS; otherwise rs_scratch is needed
+static inline bool pmx_general_lds_fits(int mat_rows, int msize, int max_rlen)
+{
+    return ((((size_t)mat_rows * msize * 2 + 15) & ~(size_t)15) + (((size_t)max_rlen + 8 + 15) & ~(size_t)15)) <= 160 * 1024;
+}
 
 // On-device traceback walk: trace tables -> run-length ops (BAM-encoded uint32 per run).
 // ops_off[k] = first slot of pair k in `ops` (capacity qlen+rlen each), nops[k] = runs written.

@@ -79,12 +79,16 @@ void pmx_general_kernel(const PmxGeneralArgs a)
     const uint8_t *q = a.qbuf + qb, *r = a.rbuf + rb;
     // mapped reference symbols live in LDS for the whole pair (the sweep reads one per lane and step;
     // fetching them from HBM inside the loop made every step wait for two dependent global loads)
-    unsigned char *rs = lds + (((size_t)a.mat_rows * msize * 2 + 15) & ~(size_t)15);
+    // (a reference too long for the LDS -- beyond ~160 k symbols -- is mapped into a per-pair HBM scratch instead and read through
+    //  the caches: slower per step, but no length limit; the reference has none either)
+    unsigned char *rs_lds = lds + (((size_t)a.mat_rows * msize * 2 + 15) & ~(size_t)15);
+    unsigned char *rs = a.rs_scratch ? a.rs_scratch + (long long)blockIdx.x * a.rs_stride : rs_lds;
     for (int j = lane; j < rl; j += 64) rs[j] = a.mapper[r[j]];
     for (int j = rl + lane; j < rl + 4; j += 64) rs[j] = 0;
+    if (a.rs_scratch) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); }
     __syncthreads();
     // optional staging area for one band of trace bytes (64 rows x rl), flushed with wide stores
-    unsigned char *tstage = rs + (((size_t)a.max_rlen + 8 + 15) & ~(size_t)15);
+    unsigned char *tstage = rs_lds + (((size_t)a.max_rlen + 8 + 15) & ~(size_t)15);
     const bool tlds = OUT && a.trace_table && a.trace_lds;
     const long long tab0 = a.tab_off ? a.tab_off[pair] : 0;
     const long long row0 = (a.n > 1 || a.index) ? rb : 0;     // row outputs packed like the references
@@ -316,10 +320,14 @@ int pmx_launch_general(const PmxGeneralArgs &a_in, bool want_stats, hipStream_t 
 {
     if (a_in.n <= 0) return 0;
     PmxGeneralArgs a = a_in;
-    size_t lds = (((size_t)a.mat_rows * a.msize * 2 + 15) & ~(size_t)15) + (((size_t)a.max_rlen + 8 + 15) & ~(size_t)15);
-    if (lds > 160 * 1024) return 1;
+    const size_t mat_bytes = ((size_t)a.mat_rows * a.msize * 2 + 15) & ~(size_t)15;
+    size_t lds = mat_bytes + (((size_t)a.max_rlen + 8 + 15) & ~(size_t)15);
+    if (lds > 160 * 1024) {                       // the reference does not fit the LDS: the caller's HBM scratch holds the mapped symbols
+        if (!a.rs_scratch || mat_bytes > 160 * 1024) return 1;
+        lds = mat_bytes;
+    } else a.rs_scratch = nullptr;
     a.trace_lds = 0;
-    if (a.trace_table && lds + (size_t)64 * a.max_rlen + 32 <= 96 * 1024) { a.trace_lds = 1; lds += (size_t)64 * a.max_rlen + 32; }
+    if (!a.rs_scratch && a.trace_table && lds + (size_t)64 * a.max_rlen + 32 <= 96 * 1024) { a.trace_lds = 1; lds += (size_t)64 * a.max_rlen + 32; }
     {
         const void *fns[4] = {(const void *)&pmx_general_kernel<true, true>, (const void *)&pmx_general_kernel<true, false>,
                               (const void *)&pmx_general_kernel<false, true>, (const void *)&pmx_general_kernel<false, false>};
