@@ -283,6 +283,24 @@ int pmx_align_profile_batch_device(const pmx_config_t *cfg, const parasail_profi
                                    const uint8_t *d_rbuf, const int64_t *d_roff, int32_t max_rlen,
                                    pmx_record_t *d_out, pmx_stats_t *d_stats_out, void *stream);
 
+/* Banded batches (extension).  The reference has one banded entry -- Aligner::banded_nw -> parasail_nw_banded above: global, main
+ * diagonal.  The batch form takes any mode and an optional per-pair band centre: cell (i, j) of pair k belongs to the band iff
+ * |(j - i) - diag[k]| <= band (diag == NULL: 0 for every pair); cells outside it cannot be entered or left.  Only the band's
+ * cells are computed (band <= 63; wider bands run the general kernel with a mask).  BASELINE config 5's "banded SW" is
+ * mode = PMX_MODE_SW with diag[k] = end_ref - end_query of a first full pass, or a seed's diagonal.  Score and end positions
+ * only; 32-bit lanes (cfg->width is ignored).  profile != NULL: the profile arm (qbuf / qoff are ignored). */
+int pmx_align_batch_banded(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,
+                           const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
+                           int32_t band, const int32_t *diag, pmx_record_t *out);
+int pmx_align_batch_banded_device(const pmx_config_t *cfg, int64_t n,
+                                  const uint8_t *d_qbuf, const int64_t *d_qoff,
+                                  const uint8_t *d_rbuf, const int64_t *d_roff,
+                                  int32_t max_qlen, int32_t max_rlen, int32_t band, const int32_t *d_diag,
+                                  pmx_record_t *d_out, void *stream);
+int pmx_align_profile_batch_banded_device(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,
+                                          const uint8_t *d_rbuf, const int64_t *d_roff, int32_t max_rlen,
+                                          int32_t band, const int32_t *d_diag, pmx_record_t *d_out, void *stream);
+
 /* CIGAR text for a batch (semi-global / global / local with traceback done on the device).
  * cigar_off has n+1 entries; *cigar_buf is malloc'd by the callee and freed with pmx_free. */
 int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,

@@ -58,6 +58,7 @@ def lib():
         _lib.orc_align_stats_sample.restype = C.c_int
         _lib.orc_cigar_sample.restype = C.c_int
         _lib.orc_rescore_cigars.restype = C.c_long
+        _lib.orc_align_banded_batch.restype = C.c_int
     return _lib
 
 
@@ -292,3 +293,26 @@ def rescore_cigars(text, toff, qbuf, qoff, rbuf, roff, open_, ext, matrix, beg=N
                                    _ptr(beg), int(open_), int(ext), int(free_mask), _ptr(matrix.scores), matrix.size,
                                    _ptr(matrix.mapper), _ptr(out))
     return out, int(bad)
+
+
+def align_banded_batch(mode, qbuf, qoff, rbuf, roff, open_, ext, matrix, band, diag=None, sg_flags=SG_ALL, shared_query=None):
+    """Banded alignment of a packed batch (cells with |(j - i) - diag| > band are excluded; diag: int32 per pair or None
+    for the main diagonal) -> int32 [n, 3]: score, end_query, end_ref."""
+    n = len(roff) - 1
+    out = np.zeros((n, 3), dtype=np.int32)
+    roff = np.ascontiguousarray(roff, dtype=np.int64)
+    if diag is not None:
+        diag = np.ascontiguousarray(diag, dtype=np.int32)
+    if shared_query is not None:
+        qb = np.frombuffer(bytes(shared_query), dtype=np.uint8)
+        rc = lib().orc_align_banded_batch(mode, sg_flags, C.c_long(n), _ptr(qb), None, len(qb), _ptr(rbuf), _ptr(roff),
+                                          int(open_), int(ext), _ptr(matrix.scores), matrix.size, _ptr(matrix.mapper),
+                                          int(band), _ptr(diag), _ptr(out))
+    else:
+        qoff = np.ascontiguousarray(qoff, dtype=np.int64)
+        rc = lib().orc_align_banded_batch(mode, sg_flags, C.c_long(n), _ptr(qbuf), _ptr(qoff), 0, _ptr(rbuf), _ptr(roff),
+                                          int(open_), int(ext), _ptr(matrix.scores), matrix.size, _ptr(matrix.mapper),
+                                          int(band), _ptr(diag), _ptr(out))
+    if rc:
+        raise RuntimeError("orc_align_banded_batch: some pair failed")
+    return out

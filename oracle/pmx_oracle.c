@@ -116,12 +116,35 @@ static int width_min(int bits) {
  *   saturation        fixed width w: flagged iff some H (boundary included) leaves [MIN_w, MAX_w];
  *                     "sat" (bits == 0) never saturates below 32 bits.
  */
+/* [UNPINNED] band (Aligner::banded_nw -> parasail_nw_banded(..., k, matrix), src/aligner/mod.rs:454-489; the one KAT,
+ * tests/test_parasail.rs:726-736, has k = 2 on identical 4-mers): a cell (i, j) (0-based) belongs to the band iff
+ * |(j - i) - diag| <= band; outside it H = E = F = -inf (set after the recurrences and the local floor, so a masked cell can
+ * neither be entered nor left).  The boundary row / column keep their values.  diag = 0 is the reference's main-diagonal band;
+ * a per-pair diag is this repo's extension for banded local alignment around a seed / a first-pass end diagonal
+ * (BASELINE config 5 "banded SW"; no reference counterpart).  band < 0: no band. */
+int orc_align_ex(int mode, int sg_flags,
+                 const uint8_t *q, int qlen, const uint8_t *r, int rlen,
+                 int open, int ext,
+                 const int32_t *matrix, int msize, const int32_t *mapper,
+                 int bits, int want_stats, int band, int diag,
+                 orc_result_t *res, orc_outputs_t *out);
+
 int orc_align(int mode, int sg_flags,
               const uint8_t *q, int qlen, const uint8_t *r, int rlen,
               int open, int ext,
               const int32_t *matrix, int msize, const int32_t *mapper,
               int bits, int want_stats,
               orc_result_t *res, orc_outputs_t *out)
+{
+    return orc_align_ex(mode, sg_flags, q, qlen, r, rlen, open, ext, matrix, msize, mapper, bits, want_stats, -1, 0, res, out);
+}
+
+int orc_align_ex(int mode, int sg_flags,
+                 const uint8_t *q, int qlen, const uint8_t *r, int rlen,
+                 int open, int ext,
+                 const int32_t *matrix, int msize, const int32_t *mapper,
+                 int bits, int want_stats, int band, int diag,
+                 orc_result_t *res, orc_outputs_t *out)
 {
     int i, j;
     int32_t *Hp, *HMp, *HSp, *HLp, *F, *FM, *FS, *FL;
@@ -190,8 +213,12 @@ int orc_align(int mode, int sg_flags,
                 H = 0; HM = HS = HL = 0;
                 T &= ~(ORC_INS | ORC_DEL | ORC_DIAG);   /* ZERO */
             }
+            if (band >= 0) {
+                const int dj = (j - 1) - (i - 1) - diag;
+                if (dj > band || dj < -band) { H = ORC_NEG_INF; E = ORC_NEG_INF; F[j] = ORC_NEG_INF; HM = HS = HL = 0; }
+            }
             if (H > hmax) hmax = H;
-            if (H < hmin) hmin = H;
+            if (H < hmin && band < 0) hmin = H;
             Hp[j] = H; HMp[j] = HM; HSp[j] = HS; HLp[j] = HL;
             WH = H; WM = HM; WS = HS; WL = HL;
             if (out->score_table)   out->score_table[(size_t)(i - 1) * rlen + (j - 1)] = H;

@@ -134,3 +134,29 @@ long orc_rescore_cigars(long n, const char *text, const int64_t *toff,
     }
     return bad;
 }
+
+int orc_align_ex(int mode, int sg_flags, const uint8_t *q, int qlen, const uint8_t *r, int rlen, int open, int ext,
+                 const int32_t *matrix, int msize, const int32_t *mapper, int bits, int want_stats, int band, int diag,
+                 orc_result_t *res, orc_outputs_t *out);
+
+/* Banded batch (see orc_align_ex): diag == NULL means the main diagonal for every pair; qoff == NULL: one shared query.
+ * out[3*k..]: score, end_query, end_ref. */
+int orc_align_banded_batch(int mode, int sg_flags, long n,
+                           const uint8_t *qbuf, const int64_t *qoff, int qshared,
+                           const uint8_t *rbuf, const int64_t *roff,
+                           int open, int ext, const int32_t *matrix, int msize, const int32_t *mapper,
+                           int band, const int32_t *diag, int32_t *out)
+{
+    long k; int bad = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(|:bad)
+    for (k = 0; k < n; ++k) {
+        const uint8_t *q = qoff ? qbuf + qoff[k] : qbuf;
+        const int qlen = qoff ? (int)(qoff[k + 1] - qoff[k]) : qshared;
+        orc_result_t res;
+        const int rc = orc_align_ex(mode, sg_flags, q, qlen, rbuf + roff[k], (int)(roff[k + 1] - roff[k]), open, ext,
+                                    matrix, msize, mapper, 0, 0, band, diag ? diag[k] : 0, &res, NULL);
+        if (rc) { bad |= 1; out[3 * k] = out[3 * k + 1] = out[3 * k + 2] = 0; continue; }
+        out[3 * k] = res.score; out[3 * k + 1] = res.end_query; out[3 * k + 2] = res.end_ref;
+    }
+    return bad;
+}

@@ -126,6 +126,12 @@ _sig("pmx_align_batch_cigar", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_v
      C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p)
 _sig("pmx_align_batch_cigar_device", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
      C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+_sig("pmx_align_batch_banded", C.c_int, C.POINTER(pmx_config_t), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+     C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
+_sig("pmx_align_batch_banded_device", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+     C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("pmx_align_profile_batch_banded_device", C.c_int, C.POINTER(pmx_config_t), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
 _libc_free = C.CDLL(None).free
 _libc_free.argtypes = [C.c_void_p]
 
@@ -747,6 +753,25 @@ class Aligner:
         if rc:
             raise BatchError(lib.pmx_last_error().decode())
         return (out, stats) if stats is not None else out
+
+    def align_batch_banded(self, queries, references, band, diag=None):
+        """Banded batch (extension): cells with |(j - i) - diag[k]| > band are excluded; score and end positions."""
+        rbuf, roff = pack(references)
+        n = len(roff) - 1
+        cfg = self._config()
+        cfg.want = 0
+        out = np.zeros(n, dtype=RECORD_DTYPE)
+        d = None if diag is None else np.ascontiguousarray(diag, dtype=np.int32)
+        if self._profile.is_null():
+            qbuf, qoff = pack(queries)
+            rc = lib.pmx_align_batch_banded(C.byref(cfg), None, n, qbuf.ctypes.data, qoff.ctypes.data, rbuf.ctypes.data,
+                                            roff.ctypes.data, int(band), d.ctypes.data if d is not None else None, out.ctypes.data)
+        else:
+            rc = lib.pmx_align_batch_banded(C.byref(cfg), self._profile.inner, n, None, None, rbuf.ctypes.data,
+                                            roff.ctypes.data, int(band), d.ctypes.data if d is not None else None, out.ctypes.data)
+        if rc:
+            raise BatchError(lib.pmx_last_error().decode())
+        return out
 
     def align_batch_cigar(self, queries, references):
         qbuf, qoff = pack(queries)

@@ -744,6 +744,9 @@ extern "C" parasail_pfunction_t *parasail_lookup_pfunction(const char *funcname)
     return make_ptable(std::make_index_sequence<N_IDS>{})[id];
 }
 
+extern "C" int pmx_align_batch_banded(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,
+                                      const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
+                                      int32_t band, const int32_t *diag, pmx_record_t *out);
 // src/aligner/mod.rs:470-481.  Cells with |i-j| > k are excluded.
 extern "C" parasail_result_t *parasail_nw_banded(const char *s1, const int s1Len, const char *s2, const int s2Len,
                                                  const int open, const int gap, const int k,
@@ -751,6 +754,22 @@ extern "C" parasail_result_t *parasail_nw_banded(const char *s1, const int s1Len
 {
     RunSpec sp; memset(&sp, 0, sizeof sp);
     sp.mode = PMX_MODE_NW; sp.band = k < 0 ? 0 : k; sp.width = 32; sp.vecflag = 0;
+    if (s1 && s2 && s1Len > 0 && s2Len > 0 && matrix && matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && sp.band <= 63 &&
+        matrix->size <= PMX_MAX_FAST_MSIZE) {
+        // the band-only kernel: O(qlen * k) cells, no length limit ("for aligning large sequences", src/aligner/mod.rs:454-456)
+        parasail_result_t *res = (parasail_result_t *)calloc(1, sizeof(parasail_result_t));
+        if (!res) die("calloc", hipSuccess);
+        res->qlen = s1Len; res->rlen = s2Len;
+        res->flag = F_NW | F_BANDED | F_BITS_32;
+        pmx_config_t cfg; memset(&cfg, 0, sizeof cfg);
+        cfg.mode = PMX_MODE_NW; cfg.open = open; cfg.extend = gap; cfg.width = 32; cfg.matrix = matrix;
+        const int64_t qo[2] = {0, s1Len}, ro[2] = {0, s2Len};
+        pmx_record_t rec;
+        if (pmx_align_batch_banded(&cfg, nullptr, 1, (const uint8_t *)s1, qo, (const uint8_t *)s2, ro, sp.band, nullptr, &rec))
+            die(g_err, hipSuccess);
+        res->score = rec.score; res->end_query = rec.end_query; res->end_ref = rec.end_ref;
+        return res;
+    }
     return run_single(sp, s1, s1Len, s2, s2Len, open, gap, matrix);
 }
 
@@ -983,7 +1002,11 @@ static int scratch_reserve(size_t bytes, void **out, int slot = SCR_BOUND)
     Scratch &g_scratch = g_scratch_pool[slot];
     int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
     if (g_scratch.dev != dev || g_scratch.cap < bytes) {
-        if (g_scratch.p && g_scratch.dev == dev) (void)hipFree(g_scratch.p);
+        if (g_scratch.p) {                                     // (a block of another device is released on that device)
+            if (g_scratch.dev != dev) (void)hipSetDevice(g_scratch.dev);
+            (void)hipFree(g_scratch.p);
+            if (g_scratch.dev != dev) (void)hipSetDevice(dev);
+        }
         g_scratch.p = nullptr; g_scratch.cap = 0; g_scratch.dev = dev;
         HIP_OR_RET(hipMalloc(&g_scratch.p, bytes ? bytes : 16));
         g_scratch.cap = bytes;
@@ -995,6 +1018,42 @@ static int scratch_reserve(size_t bytes, void **out, int slot = SCR_BOUND)
 static thread_local const char *g_last_kernel = "";
 extern "C" const char *pmx_last_kernel(void) { return g_last_kernel; }
 
+
+// General kernel (one wave per pair) over a batch.  Its scratch -- the boundary row between 64-row bands, 8 ints per reference
+// column, and for references beyond the LDS a mapped copy in HBM -- only has to cover the pairs of one launch: chunks of ~2 GB.
+// band >= 0: cells with |(j - i) - diag[pair]| > band are excluded (diag == nullptr: the main diagonal).
+static int general_batch(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
+                         const uint8_t *d_qbuf, const int64_t *d_qoff, int q_shared,
+                         const uint8_t *d_rbuf, const int64_t *d_roff, int32_t max_rlen,
+                         int band, const int32_t *d_diag, bool want_stats,
+                         pmx_record_t *d_out, pmx_stats_t *d_stats_out, hipStream_t st)
+{
+    const size_t stride = (size_t)8 * max_rlen;
+    const bool fits = pmx_general_lds_fits(dm.d.msize, dm.d.msize, max_rlen);
+    const size_t rs_stride = fits ? 0 : (((size_t)max_rlen + 8 + 15) & ~(size_t)15);
+    const size_t per_pair = stride * sizeof(int32_t) + rs_stride;
+    int64_t chunk = (int64_t)(2e9 / (double)per_pair);
+    if (chunk < 1) chunk = 1;
+    if (chunk > n) chunk = n;
+    void *bound = nullptr;
+    if (scratch_reserve((size_t)chunk * per_pair, &bound)) return -1;
+    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+        const int64_t m = (n - c0 < chunk) ? n - c0 : chunk;
+        PmxGeneralArgs a; memset(&a, 0, sizeof a);
+        a.qbuf = d_qbuf; a.qoff = q_shared ? nullptr : d_qoff + c0; a.shared_qlen = q_shared;
+        a.rbuf = d_rbuf; a.roff = d_roff + c0; a.n = m; a.max_rlen = max_rlen;
+        a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize; a.pssm = 0;
+        a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend;
+        a.band = band; a.diag = d_diag ? d_diag + c0 : nullptr;
+        a.bits = cfg->width;
+        a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
+        if (!fits) { a.rs_scratch = (uint8_t *)bound + (size_t)chunk * stride * sizeof(int32_t); a.rs_stride = (long long)rs_stride; }
+        a.rec = d_out + c0; a.stats = d_stats_out ? d_stats_out + c0 : nullptr;
+        const int rc = pmx_launch_general(a, want_stats, st);
+        if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    }
+    return 0;
+}
 
 // ---- statistics of the profile arm by traceback ------------------------------------------------------------
 // matches / similar / length are properties of the one path the coupled statistics tables follow (same decisions, same
@@ -1223,31 +1282,9 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         if (rc == 0) return 0;     // the host-side range proof makes overflow impossible: no promotion pass
     }
     if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
-    // General kernel (one wave per pair).  Its scratch -- the boundary row between 64-row bands, 8 ints per reference column, and
-    // for references beyond the LDS a mapped copy in HBM -- only has to cover the pairs of one launch: chunks of at most ~2 GB.
-    const size_t stride = (size_t)8 * max_rlen;
-    const bool fits = pmx_general_lds_fits(dm.d.msize, dm.d.msize, max_rlen);
-    const size_t rs_stride = fits ? 0 : (((size_t)max_rlen + 8 + 15) & ~(size_t)15);
-    const size_t per_pair = stride * sizeof(int32_t) + rs_stride;
-    int64_t chunk = (int64_t)(2e9 / (double)per_pair);
-    if (chunk < 1) chunk = 1;
-    if (chunk > n) chunk = n;
-    void *bound = nullptr;
-    if (scratch_reserve((size_t)chunk * per_pair, &bound)) return -1;
-    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
-        const int64_t m = (n - c0 < chunk) ? n - c0 : chunk;
-        PmxGeneralArgs a; memset(&a, 0, sizeof a);
-        a.qbuf = d_qbuf; a.qoff = q_shared ? nullptr : d_qoff + c0; a.shared_qlen = q_shared;
-        a.rbuf = d_rbuf; a.roff = d_roff + c0; a.n = m; a.max_rlen = max_rlen;
-        a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize; a.pssm = 0;
-        a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1;
-        a.bits = cfg->width;
-        a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
-        if (!fits) { a.rs_scratch = (uint8_t *)bound + (size_t)chunk * stride * sizeof(int32_t); a.rs_stride = (long long)rs_stride; }
-        a.rec = d_out + c0; a.stats = d_stats_out ? d_stats_out + c0 : nullptr;
-        const int rc = pmx_launch_general(a, (want & PMX_WANT_STATS) != 0, st);
-        if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
-    }
+    const int rcg = general_batch(cfg, dm, n, d_qbuf, d_qoff, q_shared, d_rbuf, d_roff, max_rlen, -1, nullptr,
+                                  (want & PMX_WANT_STATS) != 0, d_out, d_stats_out, st);
+    if (rcg) return rcg;
     g_last_kernel = "pmx_general_kernel";
     return 0;
 }
@@ -1339,6 +1376,10 @@ extern "C" int pmx_align_batch(const pmx_config_t *cfg, int64_t n,
         static thread_local int s_dev = -1;
         int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
         if (s_dev != dev) {
+            if (s_copy) {                                      // the thread moved to another device: release the old device's objects
+                (void)hipStreamDestroy(s_copy); (void)hipStreamDestroy(s_comp);
+                for (auto &e : s_ev) (void)hipEventDestroy(e);
+            }
             HIP_OR_RET(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
             HIP_OR_RET(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
             for (auto &e : s_ev) HIP_OR_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1418,6 +1459,88 @@ extern "C" int pmx_align_profile_batch_device(const pmx_config_t *cfg, const par
                             d_out, d_stats_out, stream, profile_has_wildcard(profile));
 }
 
+
+// ---- banded batches (extension) ------------------------------------------------------------------------------
+// The reference has one banded entry, Aligner::banded_nw -> parasail_nw_banded (src/aligner/mod.rs:454-489: global, main
+// diagonal).  The batch form takes any mode and an optional per-pair band centre: cell (i, j) belongs to the band iff
+// |(j - i) - diag[pair]| <= band.  BASELINE config 5's "banded SW" is this with mode = local and diag = end_ref - end_query of a
+// first full pass (or a seed's diagonal).  Rule and oracle: oracle/pmx_oracle.c:orc_align_ex.
+static int banded_device(const pmx_config_t *cfg, int64_t n, const uint8_t *d_qbuf, const int64_t *d_qoff, int q_shared,
+                         const uint8_t *d_rbuf, const int64_t *d_roff, int32_t max_qlen, int32_t max_rlen,
+                         int32_t band, const int32_t *d_diag, pmx_record_t *d_out, void *stream)
+{
+    if (check_cfg(cfg)) return -1;
+    if (n <= 0) return 0;
+    if (band < 0) { set_err("band must be >= 0"); return -1; }
+    if (max_qlen <= 0 || max_rlen <= 0) { set_err("max_qlen / max_rlen must be positive"); return -1; }
+    if (cfg->want & ~PMX_WANT_SORTED) { set_err("banded batches return score and end positions only"); return -1; }
+    if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
+    DevMat dm;
+    if (get_devmat(cfg->matrix, &dm)) return -1;
+    StreamGuard guard(stream);
+    if (!guard.ok) { set_err("stream guard failed"); return -1; }
+    pmx_config_t c = *cfg; c.width = 32;                       // 32-bit lanes: no saturation inside a band
+    const int rcb = pmx_launch_banded(c.mode, c.sg_flags, c.open, c.extend, dm.d, n, d_qbuf, d_qoff, q_shared, d_rbuf, d_roff,
+                                      max_qlen, max_rlen, band, d_diag, d_out, (hipStream_t)stream);
+    if (rcb < 0) { set_err("banded kernel launch failed: %s", hipGetErrorString((hipError_t)(-rcb))); return rcb; }
+    if (rcb == 0) { g_last_kernel = "pmx_banded_kernel"; return 0; }
+    const int rc = general_batch(&c, dm, n, d_qbuf, d_qoff, q_shared, d_rbuf, d_roff, max_rlen, band, d_diag, false, d_out, nullptr,
+                                 (hipStream_t)stream);
+    if (rc == 0) g_last_kernel = "pmx_general_kernel/banded";
+    return rc;
+}
+
+extern "C" int pmx_align_batch_banded_device(const pmx_config_t *cfg, int64_t n,
+                                             const uint8_t *d_qbuf, const int64_t *d_qoff,
+                                             const uint8_t *d_rbuf, const int64_t *d_roff,
+                                             int32_t max_qlen, int32_t max_rlen, int32_t band, const int32_t *d_diag,
+                                             pmx_record_t *d_out, void *stream)
+{
+    if (!d_qbuf || !d_qoff || !d_rbuf || !d_roff || !d_out) { set_err("null buffer"); return -1; }
+    return banded_device(cfg, n, d_qbuf, d_qoff, 0, d_rbuf, d_roff, max_qlen, max_rlen, band, d_diag, d_out, stream);
+}
+
+extern "C" int pmx_align_profile_batch_banded_device(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,
+                                                     const uint8_t *d_rbuf, const int64_t *d_roff, int32_t max_rlen,
+                                                     int32_t band, const int32_t *d_diag, pmx_record_t *d_out, void *stream)
+{
+    if (!profile) { set_err("null profile"); return -1; }
+    if (!cfg || profile->matrix != cfg->matrix) { set_err("profile was built with a different matrix"); return -1; }
+    if (!d_rbuf || !d_roff || !d_out) { set_err("null buffer"); return -1; }
+    const uint8_t *dq = nullptr;
+    if (profile_device_query(profile, &dq)) return -1;
+    return banded_device(cfg, n, dq, nullptr, profile->s1Len, d_rbuf, d_roff, profile->s1Len, max_rlen, band, d_diag, d_out, stream);
+}
+
+// Host buffers in, host records out.  profile != NULL: the profile arm (qbuf / qoff are ignored).
+extern "C" int pmx_align_batch_banded(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,
+                                      const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
+                                      int32_t band, const int32_t *diag, pmx_record_t *out)
+{
+    if (check_cfg(cfg)) return -1;
+    if (n <= 0) return 0;
+    if (!rbuf || !roff || !out || (!profile && (!qbuf || !qoff))) { set_err("null buffer"); return -1; }
+    int32_t mq = 0, mr = 0; bool bad = false;
+    host_maxlens(n, roff, &mr, &bad);
+    if (!profile) host_maxlens(n, qoff, &mq, &bad); else mq = profile->s1Len;
+    if (bad || roff[0] != 0 || (!profile && qoff[0] != 0)) { set_err("bad offsets (every sequence needs length >= 1, offsets start at 0)"); return -1; }
+    DevBuf<uint8_t> dq, dr; DevBuf<int64_t> dqo, dro; DevBuf<int32_t> dd; DevBuf<pmx_record_t> drec;
+    if (dr.try_alloc((size_t)roff[n]) || dro.try_alloc(n + 1) || drec.try_alloc(n) || (diag && dd.try_alloc(n)) ||
+        (!profile && (dq.try_alloc((size_t)qoff[n]) || dqo.try_alloc(n + 1)))) { set_err("out of device memory"); return -2; }
+    HIP_OR_RET(hipMemcpy(dr.p, rbuf, (size_t)roff[n], hipMemcpyHostToDevice));
+    HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    if (diag) HIP_OR_RET(hipMemcpy(dd.p, diag, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    int rc;
+    if (profile) rc = pmx_align_profile_batch_banded_device(cfg, profile, n, dr.p, dro.p, mr, band, diag ? dd.p : nullptr, drec.p, nullptr);
+    else {
+        HIP_OR_RET(hipMemcpy(dq.p, qbuf, (size_t)qoff[n], hipMemcpyHostToDevice));
+        HIP_OR_RET(hipMemcpy(dqo.p, qoff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+        rc = pmx_align_batch_banded_device(cfg, n, dq.p, dqo.p, dr.p, dro.p, mq, mr, band, diag ? dd.p : nullptr, drec.p, nullptr);
+    }
+    if (rc) return rc;
+    HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 // ---- device-resident CIGAR entry ------------------------------------------------------------------------
 // Sweep (packed 4-bit traceback to HBM scratch) and walk run in chunks on two streams: the walk of chunk c (latency-bound, one

@@ -122,7 +122,8 @@ struct PmxGeneralArgs {
     int mat_rows;             // rows of `scores`: msize for a square matrix, query length for a PSSM
     int pssm;                 // 1: row of `scores` is the query position, not the query symbol
     int mode, sg_flags, open, ext;
-    int band;                 // < 0: no band; else cells with |i-j| > band are excluded (nw_banded)
+    int band;                 // < 0: no band; else cells with |(j - i) - diag[pair]| > band are excluded (nw_banded: diag == nullptr)
+    const int32_t *diag;      // optional per-pair band centre (indexed like roff)
     int bits;                 // 0/32/64: no range check; 8 or 16: report saturation of that range
     // per-pair scratch: boundary row between 64-row bands, 8 ints per reference column
     int32_t *bound; long long bound_stride;       // ints per pair
@@ -145,6 +146,12 @@ static inline bool pmx_general_lds_fits(int mat_rows, int msize, int max_rlen)
 {
     return ((((size_t)mat_rows * msize * 2 + 15) & ~(size_t)15) + (((size_t)max_rlen + 8 + 15) & ~(size_t)15)) <= 160 * 1024;
 }
+
+// Banded fast kernel (pmx_banded.hip): lanes over the band's diagonals, one query row per step, only the band's cells are
+// computed.  0 launched, 1 not eligible (the general kernel masks instead), <0 HIP error.
+int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,
+                      const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
+                      int max_qlen, int max_rlen, int band, const int32_t *diag, pmx_record_t *out, hipStream_t stream);
 
 // On-device traceback walk: trace tables -> run-length ops (BAM-encoded uint32 per run).
 // ops_off[k] = first slot of pair k in `ops` (capacity qlen+rlen each), nops[k] = runs written.

@@ -96,6 +96,7 @@ void pmx_general_kernel(const PmxGeneralArgs a)
     int32_t *bound = a.bound + (long long)blockIdx.x * a.bound_stride;
 
     const int mode = a.mode, open = a.open, ext = a.ext, band_w = a.band;
+    const int band_d = a.diag ? a.diag[pair] : 0;             // band centre: cells with |(j - i) - band_d| > band_w are excluded
     const bool s1_beg = mode == PMX_MODE_SG && (a.sg_flags & PMX_SG_QB);
     const bool s1_end = mode == PMX_MODE_SG && (a.sg_flags & PMX_SG_QE);
     const bool s2_beg = mode == PMX_MODE_SG && (a.sg_flags & PMX_SG_DB);
@@ -199,7 +200,7 @@ void pmx_general_kernel(const PmxGeneralArgs a)
                 if (mode == PMX_MODE_SW && H <= 0) {
                     H = 0; HM = HS = HL = 0; T &= ~(T_INS | T_DEL | T_DIAG);
                 }
-                if (band_w >= 0 && (i - j > band_w || j - i > band_w)) {
+                if (band_w >= 0 && (j - i - band_d > band_w || j - i - band_d < -band_w)) {
                     H = NEG_INF; E = NEG_INF; F = NEG_INF; HM = HS = HL = 0;
                 }
                 hmax = max(hmax, H);

@@ -1,0 +1,131 @@
+"""Banded alignment (`-m gpu`): Aligner::banded_nw (/root/reference/src/aligner/mod.rs:454-489, KAT tests/test_parasail.rs:726-736)
+against the banded oracle on NARROW bands, the batch extension (any mode, per-pair band centre: BASELINE config 5's "banded SW"),
+and inputs beyond every LDS-resident limit (long references in the general kernel, long pairs in the band-only kernel)."""
+import numpy as np
+import pytest
+
+import workloads as wl
+from util import random_seqs, mutate, DNA, AA
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 8, 32, 63, 64, 400])
+def test_banded_nw_narrow_bands_match_the_banded_oracle(pkg, orc, k):
+    """one pair per call through Aligner::banded_nw; k <= 63 runs the band-only kernel, wider bands the masked general kernel"""
+    rng = np.random.default_rng(8100 + k)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    al = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).bandwidth(k).build()
+    qs = random_seqs(rng, 24, 1, 220)
+    rs = [mutate(rng, q, 0.1, 0.05) if i % 3 else random_seqs(rng, 1, 1, 260)[0] for i, q in enumerate(qs)]
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    want = orc.align_banded_batch(orc.NW, qb, qo, rb, ro, 5, 2, om, k)
+    full = orc.align_batch(orc.NW, qb, qo, rb, ro, 5, 2, om)
+    for t, (q, r) in enumerate(zip(qs, rs)):
+        res = al.banded_nw(q, r)
+        assert res.is_banded() and res.is_global()
+        assert (res.get_score(), res.get_end_query(), res.get_end_ref()) == tuple(want[t]), (k, t, len(q), len(r))
+    assert (want[:, 0] <= full[:, 0]).all()
+    if k == 400:
+        assert (want[:, 0] == full[:, 0]).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("k", [3, 15, 16, 31, 32, 63, 100])
+def test_banded_batch_every_mode_with_band_centres(pkg, orc, mode, k):
+    rng = np.random.default_rng(8200 + 10 * k + mode)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    n = 300
+    qs = random_seqs(rng, n, 1, 180)
+    rs = []
+    diag = np.zeros(n, dtype=np.int32)
+    for t, q in enumerate(qs):
+        body = mutate(rng, q, 0.08, 0.04)
+        pre = random_seqs(rng, 1, 0, 60)[0] if t % 2 else b""
+        rs.append(pre + body + (random_seqs(rng, 1, 0, 40)[0] if t % 5 == 0 else b""))
+        diag[t] = len(pre) + int(rng.integers(-4, 5))            # the band follows the planted copy, a little off-centre
+    b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2)
+    [b.global_, b.semi_global, b.local][mode]()
+    al = b.build()
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    for dg in (None, diag):
+        got = al.align_batch_banded(qs, rs, k, dg)
+        kernel = pkg.lib.pmx_last_kernel().decode()
+        assert ("pmx_banded_kernel" in kernel) == (k <= 63), kernel
+        want = orc.align_banded_batch(mode, qb, qo, rb, ro, 5, 2, om, k, dg)
+        bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
+        assert len(bad) == 0, (mode, k, dg is None, bad[:5], got[bad[:3]], want[bad[:3]], [(len(qs[x]), len(rs[x])) for x in bad[:3]])
+
+
+def test_banded_batch_sg_variants_and_protein(pkg, orc):
+    rng = np.random.default_rng(8300)
+    pm = pkg.Matrix.from_name("blosum62")
+    om = orc.Matrix.from_file("tests/golden/blosum62.txt")
+    qs = random_seqs(rng, 200, 5, 150, AA)
+    rs = [mutate(rng, q, 0.3, 0.05, AA) + random_seqs(rng, 1, 0, 30, AA)[0] for q in qs]
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    for sg, qg, dg in ((orc.S1_BEG | orc.S2_END, ["prefix"], ["suffix"]), (orc.S1_END, ["suffix"], []), (orc.S2_BEG | orc.S2_END, [], ["prefix", "suffix"])):
+        al = pkg.Aligner.new().matrix(pm).gap_open(11).gap_extend(1).semi_global().allow_query_gaps(qg).allow_ref_gaps(dg).build()
+        got = al.align_batch_banded(qs, rs, 20)
+        want = orc.align_banded_batch(orc.SG, qb, qo, rb, ro, 11, 1, om, 20, sg_flags=sg)
+        assert (got["score"] == want[:, 0]).all() and (got["end_query"] == want[:, 1]).all() and (got["end_ref"] == want[:, 2]).all(), sg
+
+
+def test_cfg5_banded_sw_second_pass(pkg, orc):
+    """BASELINE config 5's "banded SW": a first full pass (`sw_striped_profile_sat`) gives every pair's end cell; the banded pass
+    around that cell's diagonal reproduces the full score wherever the optimal path stays inside the band (every planted copy:
+    1 % indels drift a few columns), never exceeds it elsewhere, and agrees with the banded oracle on a sample."""
+    n = 20000
+    q, rbuf, roff, planted = wl.make_cfg5(n, rank=2)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    prof = pkg.Profile.new(q, False, pm)
+    al = pkg.Aligner.new().local().profile(prof).matrix(pm).gap_open(5).gap_extend(2).build()
+    full = al.align_batch_packed(None, None, rbuf, roff)
+    diag = (full["end_ref"] - full["end_query"]).astype(np.int32)
+    rs = [rbuf[roff[k]:roff[k + 1]].tobytes() for k in range(n)]
+    band = 48
+    got = al.align_batch_banded([], rs, band, diag)
+    assert "pmx_banded_kernel" in pkg.lib.pmx_last_kernel().decode()
+    assert (got["score"] <= full["score"]).all()
+    assert (got["score"][planted] == full["score"][planted]).all()
+    assert (got["end_query"][planted] == full["end_query"][planted]).all() and (got["end_ref"][planted] == full["end_ref"][planted]).all()
+    idx = np.unique(np.concatenate([planted[:60], np.arange(0, n, 257)]))
+    sub_r = [rs[k] for k in idx]
+    rb2, ro2 = orc.pack(sub_r)
+    want = orc.align_banded_batch(orc.SW, None, None, rb2, ro2, 5, 2, om, band, diag[idx], shared_query=q)
+    assert (got["score"][idx] == want[:, 0]).all() and (got["end_query"][idx] == want[:, 1]).all() and (got["end_ref"][idx] == want[:, 2]).all()
+
+
+def test_long_pairs_have_no_length_limit(pkg, orc):
+    """ nothing on the path may abort on long inputs: the band-only kernel takes 300 kbp x 300 kbp pairs (the reference
+    offers banded_nw "for aligning large sequences"), and a plain striped call whose reference does not fit the LDS runs in the
+    general kernel from an HBM copy of the reference."""
+    rng = np.random.default_rng(8400)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    L = 300_000
+    q = DNA[rng.integers(0, 4, size=L)]
+    r = q.copy()
+    pos = np.sort(rng.choice(L, size=300, replace=False))
+    r[pos] = DNA[(np.searchsorted(DNA, r[pos]) + 1) % 4]                     # 300 substitutions, no indels: the path is the main diagonal
+    res = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).bandwidth(32).build().banded_nw(q.tobytes(), r.tobytes())
+    assert res.get_score() == 2 * (L - 300) - 3 * 300 and res.get_end_query() == L - 1 and res.get_end_ref() == L - 1
+    # a medium case with indels against the banded oracle (20 kbp: the oracle sweeps every cell)
+    q2 = DNA[rng.integers(0, 4, size=20000)].tobytes()
+    r2 = mutate(rng, q2, 0.05, 0.004)
+    qb, qo = orc.pack([q2]); rb, ro = orc.pack([r2])
+    for k in (16, 63):
+        res = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).bandwidth(k).build().banded_nw(q2, r2)
+        w = orc.align_banded_batch(orc.NW, qb, qo, rb, ro, 5, 2, om, k)[0]
+        assert (res.get_score(), res.get_end_query(), res.get_end_ref()) == tuple(w), k
+    # one-off local alignment, query beyond 2 048 rows, reference beyond the 160 KB of LDS
+    q3 = DNA[rng.integers(0, 4, size=2100)].tobytes()
+    r3 = bytearray(DNA[rng.integers(0, 4, size=170_000)].tobytes())
+    r3[90_000:90_000 + 2100] = mutate(rng, q3, 0.03, 0.01)[:2100].ljust(2100, b"A")
+    r3 = bytes(r3)
+    al = pkg.Aligner.new().local().matrix(pm).gap_open(5).gap_extend(2).solution_width(16).build()
+    res = al.align(q3, r3)
+    w = orc.align(orc.SW, q3, r3, 5, 2, om)
+    assert (res.get_score(), res.get_end_query(), res.get_end_ref()) == (w.score, w.end_query, w.end_ref)
+    st = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).use_stats().build().align(q3[:300], r3)
+    w = orc.align(orc.NW, q3[:300], r3, 5, 2, om, stats=True)
+    assert (st.get_score(), st.get_matches(), st.get_length()) == (w.score, w.matches, w.length)
