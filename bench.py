@@ -397,6 +397,49 @@ class Cfg5(Workload):
         self.pkg.align_profile_batch_device(self.cfg, self.profile, self.n, self.d[0].data_ptr(), self.d[1].data_ptr(),
                                             self.max_rlen, self.d_out[k % 2].data_ptr(), None, stream.cuda_stream)
 
+    def extra(self):
+        """The "banded SW" arm of config 5 (an extension: the reference has banded_nw only): a second pass restricted to
+        |(j - i) - diag| <= band around the diagonal of the first pass's end cell, band-only kernel (pmx_banded.hip)."""
+        t = self.torch
+        band = 48
+        rec = self.d_out[self.last_k % 2]
+        d_diag = (rec[:, 2] - rec[:, 1]).contiguous()
+        d_out = t.zeros((self.n, 4), dtype=t.int32, device=self.dev)
+        stream = t.cuda.current_stream(self.dev)
+        cfg = self.pkg.pmx_config_t(self.pkg.MODE_SW, 0, wl.CFG5["open"], wl.CFG5["ext"], 0, 0, self.matrix.inner)
+
+        def once():
+            rc = self.pkg.lib.pmx_align_profile_batch_banded_device(C.byref(cfg), self.profile.inner, self.n, self.d[0].data_ptr(),
+                                                                    self.d[1].data_ptr(), self.max_rlen, band, d_diag.data_ptr(),
+                                                                    d_out.data_ptr(), stream.cuda_stream)
+            if rc:
+                raise RuntimeError(self.pkg.lib.pmx_last_error().decode())
+        once(); t.cuda.synchronize(self.dev)
+        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        reps = 3
+        e0.record(stream)
+        for _ in range(reps):
+            once()
+        e1.record(stream); t.cuda.synchronize(self.dev)
+        ms = e0.elapsed_time(e1) / reps
+        rl = (self.h[1][1:] - self.h[1][:-1]).astype(np.int64)
+        dg = d_diag.cpu().numpy().astype(np.int64)
+        ql = wl.CFG5["qlen"]
+        # band cells of a pair: for every query row i the columns j in [i + diag - band, i + diag + band] inside [0, rlen)
+        i = np.arange(ql, dtype=np.int64)[None, :]
+        sample = np.arange(0, self.n, max(1, self.n // 4096))
+        lo = np.maximum(i + dg[sample, None] - band, 0); hi = np.minimum(i + dg[sample, None] + band, rl[sample, None] - 1)
+        band_cells = float(np.maximum(hi - lo + 1, 0).sum()) * (self.n / len(sample))
+        same = bool((d_out[:, 0] <= rec[:, 0]).all().item())
+        kept = float((d_out[:, 0] == rec[:, 0]).float().mean().item())
+        return {"banded_sw": {"band": band, "ms": round(ms, 3), "pairs_per_s": round(self.n / (ms * 1e-3)),
+                              "band_gcups": round(band_cells / (ms * 1e-3) / 1e9, 1),
+                              "full_matrix_equivalent_gcups": round(self.cells / (ms * 1e-3) / 1e9, 1),
+                              "kernel": self.pkg.lib.pmx_last_kernel().decode(),
+                              "never_above_full_pass": same, "share_of_pairs_with_the_full_score": round(kept, 4),
+                              "note": "extension, no reference counterpart: |(j - i) - diag| <= band with diag = end_ref - end_query of "
+                                      "the first pass; only the band's cells are computed (32-bit lanes)"}}
+
     def cpu_baseline(self, last_out):
         from oracle import oracle as orc
         c = wl.CFG5
@@ -570,6 +613,8 @@ def main():
         if world == 1 and not multi and args.pairs is None and not args.no_cpu_baseline and hasattr(w, "pcie_inclusive"):
             # the same batch handed over in host memory (H2D + kernels + D2H inside): reported beside, never as `value`
             line["pcie_inclusive"] = w.pcie_inclusive()
+        if world == 1 and not multi and hasattr(w, "extra"):
+            line.update(w.extra())
         if world == 1 and not args.no_cpu_baseline:
             last_out = w.records(w.last_k).cpu().numpy()
             line["cpu_baseline"] = w.cpu_baseline(last_out)

@@ -323,6 +323,20 @@ int pmx_align_batch_cigar_device(const pmx_config_t *cfg, int64_t n,
                                  pmx_record_t *d_out, char *d_cigar_text, int64_t cigar_capacity,
                                  int64_t *d_cigar_off, void *stream);
 
+/* Multi-GPU (one process driving several GPUs of a node).  Pairs are independent, so the batch is cut into ndev contiguous
+ * blocks with about equal numbers of cells (sum of qlen * rlen; pmx_shard_bounds_by_cells is the planner), block g runs on
+ * devices[g] from its own persistent host thread, and every block's records land in `out` at its pairs' positions: input order,
+ * no collective.  A device may be listed more than once.  (One process per GPU instead: shard with the same planner and gather
+ * the 16-byte records, e.g. RCCL over xGMI -- see INTEGRATION.md.) */
+int pmx_align_batch_multi(const pmx_config_t *cfg, int64_t n,
+                          const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
+                          const int *devices, int ndev, pmx_record_t *out, pmx_stats_t *stats_out);
+int pmx_align_profile_batch_multi(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,
+                                  const uint8_t *rbuf, const int64_t *roff,
+                                  const int *devices, int ndev, pmx_record_t *out, pmx_stats_t *stats_out);
+/* bounds[0..parts]: block g = pairs [bounds[g], bounds[g+1]).  qoff == NULL: one shared query.  Pure host arithmetic. */
+int pmx_shard_bounds_by_cells(int64_t n, const int64_t *qoff, const int64_t *roff, int parts, int64_t *bounds);
+
 /* Runtime. */
 int pmx_device_count(void);
 int pmx_set_device(int device);            /* per calling thread, like hipSetDevice */

@@ -132,6 +132,11 @@ _sig("pmx_align_batch_banded_device", C.c_int, C.POINTER(pmx_config_t), C.c_int6
      C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("pmx_align_profile_batch_banded_device", C.c_int, C.POINTER(pmx_config_t), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("pmx_align_batch_multi", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
+_sig("pmx_align_profile_batch_multi", C.c_int, C.POINTER(pmx_config_t), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
+_sig("pmx_shard_bounds_by_cells", C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 _libc_free = C.CDLL(None).free
 _libc_free.argtypes = [C.c_void_p]
 
@@ -754,6 +759,24 @@ class Aligner:
             raise BatchError(lib.pmx_last_error().decode())
         return (out, stats) if stats is not None else out
 
+    def align_batch_multi(self, qbuf, qoff, rbuf, roff, devices):
+        """One batch across several GPUs of the node (cell-balanced contiguous blocks, records in input order)."""
+        n = len(roff) - 1
+        cfg = self._config()
+        out = np.zeros(n, dtype=RECORD_DTYPE)
+        stats = np.zeros(n, dtype=STATS_DTYPE) if cfg.want & WANT_STATS else None
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        if self._profile.is_null():
+            rc = lib.pmx_align_batch_multi(C.byref(cfg), n, qbuf.ctypes.data, qoff.ctypes.data, rbuf.ctypes.data, roff.ctypes.data,
+                                           dev.ctypes.data, len(dev), out.ctypes.data, stats.ctypes.data if stats is not None else None)
+        else:
+            rc = lib.pmx_align_profile_batch_multi(C.byref(cfg), self._profile.inner, n, rbuf.ctypes.data, roff.ctypes.data,
+                                                   dev.ctypes.data, len(dev), out.ctypes.data,
+                                                   stats.ctypes.data if stats is not None else None)
+        if rc:
+            raise BatchError(lib.pmx_last_error().decode())
+        return (out, stats) if stats is not None else out
+
     def align_batch_banded(self, queries, references, band, diag=None):
         """Banded batch (extension): cells with |(j - i) - diag[k]| > band are excluded; score and end positions."""
         rbuf, roff = pack(references)
@@ -856,6 +879,17 @@ def align_profile_batch_device(cfg, profile, n, d_rbuf, d_roff, max_rlen, d_out,
     rc = lib.pmx_align_profile_batch_device(C.byref(cfg), profile.inner, n, d_rbuf, d_roff, max_rlen, d_out, d_stats, stream)
     if rc:
         raise BatchError(lib.pmx_last_error().decode())
+
+
+def shard_bounds_by_cells(qoff, roff, parts):
+    """The C planner behind pmx_align_batch_multi (qoff None: one shared query)."""
+    roff = np.ascontiguousarray(roff, dtype=np.int64)
+    n = len(roff) - 1
+    b = np.zeros(parts + 1, dtype=np.int64)
+    q = None if qoff is None else np.ascontiguousarray(qoff, dtype=np.int64)
+    if lib.pmx_shard_bounds_by_cells(n, q.ctypes.data if q is not None else None, roff.ctypes.data, parts, b.ctypes.data):
+        raise BatchError("planner failed")
+    return [int(x) for x in b]
 
 
 def version():

@@ -13,8 +13,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -1926,6 +1929,138 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
     text.p[text.len] = 0;
     *cigar_buf = text.p;
     return 0;
+}
+
+
+// ============================================================================= multi-GPU ===
+// Pairs are independent (the reference's only parallel story is user threads sharing a read-only profile,
+// tests/test_parasail.rs:689-723), so a batch shards across the GPUs of a node with no data-path collective: a contiguous block
+// of pairs per device, cut so that every device gets about the same number of cells (sum of qlen * rlen), one host thread and one
+// set of streams per device, results written straight into the caller's arrays in input order -- with one process driving all
+// GPUs the per-device D2H copy IS the gather (one process per GPU + an RCCL gather: parasail-rs_amd/sharding.py, bench.py).
+extern "C" int pmx_shard_bounds_by_cells(int64_t n, const int64_t *qoff /* NULL: one shared query */, const int64_t *roff,
+                                         int parts, int64_t *bounds /* parts + 1 */)
+{
+    if (n < 0 || parts <= 0 || !roff || !bounds) return -1;
+    // cumulative cells (a shared query weighs every reference by the same factor: the reference lengths alone decide)
+    std::vector<double> cum((size_t)n + 1);
+    cum[0] = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        const double ql = qoff ? (double)(qoff[k + 1] - qoff[k]) : 1.0;
+        cum[k + 1] = cum[k] + ql * (double)(roff[k + 1] - roff[k]);
+    }
+    bounds[0] = 0;
+    for (int g = 1; g < parts; ++g) {
+        const double target = cum[n] * (double)g / (double)parts;
+        int64_t k = (int64_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        if (k < bounds[g - 1]) k = bounds[g - 1];
+        if (k > n) k = n;
+        bounds[g] = k;
+    }
+    bounds[parts] = n;
+    return 0;
+}
+
+namespace {
+struct ShardJob {
+    const pmx_config_t *cfg; const parasail_profile_t *profile;
+    int64_t lo, hi;
+    const uint8_t *qbuf; const int64_t *qoff; const uint8_t *rbuf; const int64_t *roff;
+    pmx_record_t *out; pmx_stats_t *stats;
+    int device, rc; char err[256];
+};
+// One persistent host thread per shard slot: its thread-local device scratch, streams and staging survive between calls.
+struct ShardWorker {
+    std::thread th; std::mutex mx; std::condition_variable cv;
+    ShardJob *job = nullptr; bool done = true;
+    void loop()
+    {
+        for (;;) {
+            ShardJob *j;
+            { std::unique_lock<std::mutex> lk(mx); cv.wait(lk, [&] { return job != nullptr; }); j = job; }
+            run(*j);
+            { std::lock_guard<std::mutex> lk(mx); job = nullptr; done = true; }
+            cv.notify_all();
+        }
+    }
+    static void run(ShardJob &j)
+    {
+        j.rc = 0; j.err[0] = 0;
+        if (hipSetDevice(j.device) != hipSuccess) { j.rc = -1; snprintf(j.err, sizeof j.err, "hipSetDevice(%d) failed", j.device); return; }
+        const int64_t m = j.hi - j.lo;
+        if (m <= 0) return;
+        std::vector<int64_t> ro((size_t)m + 1), qo;
+        for (int64_t k = 0; k <= m; ++k) ro[k] = j.roff[j.lo + k] - j.roff[j.lo];
+        if (j.profile) {
+            j.rc = pmx_align_profile_batch(j.cfg, j.profile, m, j.rbuf + j.roff[j.lo], ro.data(), j.out + j.lo, j.stats ? j.stats + j.lo : nullptr);
+        } else {
+            qo.resize((size_t)m + 1);
+            for (int64_t k = 0; k <= m; ++k) qo[k] = j.qoff[j.lo + k] - j.qoff[j.lo];
+            j.rc = pmx_align_batch(j.cfg, m, j.qbuf + j.qoff[j.lo], qo.data(), j.rbuf + j.roff[j.lo], ro.data(), j.out + j.lo,
+                                   j.stats ? j.stats + j.lo : nullptr);
+        }
+        if (j.rc) snprintf(j.err, sizeof j.err, "device %d: %s", j.device, pmx_last_error());
+    }
+};
+std::mutex g_pool_mx;
+std::vector<ShardWorker *> g_pool;
+}  // namespace
+
+static int multi_run(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,
+                     const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
+                     const int *devices, int ndev, pmx_record_t *out, pmx_stats_t *stats_out)
+{
+    if (check_cfg(cfg)) return -1;
+    if (n <= 0) return 0;
+    if (!devices || ndev <= 0 || ndev > 64) { set_err("bad device list"); return -1; }
+    if (!rbuf || !roff || !out || (!profile && (!qbuf || !qoff))) { set_err("null buffer"); return -1; }
+    if ((cfg->want & PMX_WANT_STATS) && !stats_out) { set_err("stats requested without a stats buffer"); return -1; }
+    const int have = pmx_device_count();
+    for (int g = 0; g < ndev; ++g) if (devices[g] < 0 || devices[g] >= have) { set_err("device %d of the list does not exist (%d visible)", devices[g], have); return -1; }
+    std::vector<int64_t> bounds((size_t)ndev + 1);
+    if (pmx_shard_bounds_by_cells(n, profile ? nullptr : qoff, roff, ndev, bounds.data())) { set_err("shard planner failed"); return -1; }
+    std::lock_guard<std::mutex> call_lock(g_pool_mx);          // one multi-GPU call at a time per process (the workers are shared)
+    while ((int)g_pool.size() < ndev) {
+        ShardWorker *w = new ShardWorker;
+        w->th = std::thread([w] { w->loop(); });
+        w->th.detach();
+        g_pool.push_back(w);
+    }
+    std::vector<ShardJob> jobs((size_t)ndev);
+    for (int g = 0; g < ndev; ++g) {
+        ShardJob &j = jobs[g];
+        j.cfg = cfg; j.profile = profile; j.lo = bounds[g]; j.hi = bounds[g + 1];
+        j.qbuf = qbuf; j.qoff = qoff; j.rbuf = rbuf; j.roff = roff; j.out = out; j.stats = stats_out; j.device = devices[g]; j.rc = 0; j.err[0] = 0;
+        ShardWorker *w = g_pool[g];
+        { std::lock_guard<std::mutex> lk(w->mx); w->job = &j; w->done = false; }
+        w->cv.notify_all();
+    }
+    int rc = 0;
+    for (int g = 0; g < ndev; ++g) {
+        ShardWorker *w = g_pool[g];
+        std::unique_lock<std::mutex> lk(w->mx);
+        w->cv.wait(lk, [&] { return w->done; });
+        if (jobs[g].rc && !rc) { rc = jobs[g].rc; set_err("%s", jobs[g].err); }
+    }
+    return rc;
+}
+
+extern "C" int pmx_align_batch_multi(const pmx_config_t *cfg, int64_t n,
+                                     const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
+                                     const int *devices, int ndev, pmx_record_t *out, pmx_stats_t *stats_out)
+{
+    if (n > 0 && qoff && roff && (qoff[0] != 0 || roff[0] != 0)) { set_err("offset arrays must start at 0"); return -1; }
+    return multi_run(cfg, nullptr, n, qbuf, qoff, rbuf, roff, devices, ndev, out, stats_out);
+}
+
+extern "C" int pmx_align_profile_batch_multi(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,
+                                             const uint8_t *rbuf, const int64_t *roff,
+                                             const int *devices, int ndev, pmx_record_t *out, pmx_stats_t *stats_out)
+{
+    if (!profile) { set_err("null profile"); return -1; }
+    if (cfg && profile->matrix != cfg->matrix) { set_err("profile was built with a different matrix"); return -1; }
+    if (n > 0 && roff && roff[0] != 0) { set_err("offset arrays must start at 0"); return -1; }
+    return multi_run(cfg, profile, n, nullptr, nullptr, rbuf, roff, devices, ndev, out, stats_out);
 }
 
 extern "C" void pmx_free(void *p) { free(p); }

@@ -285,7 +285,7 @@ void pmx_general_kernel(const PmxGeneralArgs a)
     if (lane == 0) {
         Cand res;
         if (mode == PMX_MODE_SW) res = best_sw;
-        else if (mode == PMX_MODE_NW || (!s1_end && !s2_end)) res = corner;
+        else if (mode == PMX_MODE_NW || (!s1_end && !s2_end)) { res = corner; res.i = ql - 1; res.j = rl - 1; }   // (also when a band excludes the corner: -inf there)
         else {
             res = best_row;                                   // NEG_INF when the ref end is not free
             if (s1_end && best_col.H > res.H) res = best_col; // last column must be strictly better

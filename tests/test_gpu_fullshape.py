@@ -256,3 +256,62 @@ def _sw_begins(rec, res, o, t, n):
                 rc += c
         beg[k] = (rec[k, 1] + 1 - qc, rec[k, 2] + 1 - rc)
     return beg
+
+
+def test_multi_gpu_entry_with_one_device_listed_twice(pkg, orc):
+    """pmx_align_batch_multi / pmx_align_profile_batch_multi: two shards on two host threads (both on device 0 here; the
+    driver's node has eight GPUs), cell-balanced blocks, records in input order: identical to the single-device entries."""
+    ndev = pkg.lib.pmx_device_count()
+    devices = [0, 0] if ndev < 2 else [0, 1]
+    # config 2's shape
+    qbuf, qoff, rbuf, roff = wl.make_cfg2(300_000, rank=4)
+    pm = pkg.Matrix.create(b"ACGT", 2, -3)
+    al = pkg.Aligner.new().local().matrix(pm).gap_open(5).gap_extend(2).solution_width(16).build()
+    one = al.align_batch_packed(qbuf, qoff, rbuf, roff)
+    for devs in (devices, [0, 0, 0]):
+        two = al.align_batch_multi(qbuf, qoff, rbuf, roff, devs)
+        assert (two == one).all()
+    two = al.align_batch_multi(qbuf, qoff, rbuf, roff, devices)          # the workers' staging is reused
+    assert (two == one).all()
+    # config 5's shape (mixed lengths: the cut balances cells), profile arm; and config 3's with statistics
+    q, rb, ro, _ = wl.make_cfg5(6000, rank=6)
+    alp = pkg.Aligner.new().local().profile(pkg.Profile.new(q, False, pm)).matrix(pm).gap_open(5).gap_extend(2).build()
+    assert (alp.align_batch_multi(None, None, rb, ro, devices) == alp.align_batch_packed(None, None, rb, ro)).all()
+    q3, rb3, ro3 = wl.make_cfg3(1500, rank=2)
+    b62 = pkg.Matrix.from_name("blosum62")
+    al3 = pkg.Aligner.new().profile(pkg.Profile.new(q3, True, b62)).matrix(b62).gap_open(11).gap_extend(1).solution_width(16).build()
+    r1, s1 = al3.align_batch_packed(None, None, rb3, ro3)
+    r2, s2 = al3.align_batch_multi(None, None, rb3, ro3, devices)
+    assert (r1 == r2).all() and (s1 == s2).all()
+    with pytest.raises(pkg.BatchError):
+        al.align_batch_multi(qbuf, qoff, rbuf, roff, [0, 99])
+
+
+def test_two_streams_from_one_thread_share_the_scratch_safely(pkg, orc):
+    """ the device entries keep scratch per host thread: two batches queued back to back on two different
+    streams by ONE thread must not overwrite each other's length-sort permutation / retry list while kernels still read them."""
+    import torch
+    dev = torch.device("cuda", 0)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    q, rb, ro, _ = wl.make_cfg5(40000, rank=11)
+    qa = np.frombuffer(q, dtype=np.uint8)
+    batches = []
+    for k, (lo, hi) in enumerate(((0, 25000), (25000, 40000))):
+        r = rb[ro[lo]:ro[hi]]; o = ro[lo:hi + 1] - ro[lo]
+        m = hi - lo
+        qb = np.tile(qa, m); qo = wl.uniform_offsets(m, 1000)
+        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (qb, qo, r, o)]
+        out = torch.zeros((m, 4), dtype=torch.int32, device=dev)
+        batches.append((m, d, out, int((o[1:] - o[:-1]).max())))
+    cfg = pkg.pmx_config_t(pkg.MODE_SW, 0, 5, 2, 0, pkg.WANT_SORTED, pm.inner)       # length-sorted order: scratch in play
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for (m, d, out, mr), st in zip(batches, streams):
+            pkg.align_batch_device(cfg, m, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 1000, mr,
+                                   out.data_ptr(), None, st.cuda_stream)
+    torch.cuda.synchronize()
+    al = pkg.Aligner.new().local().profile(pkg.Profile.new(q, False, pm)).matrix(pm).gap_open(5).gap_extend(2).build()
+    want = al.align_batch_packed(None, None, rb, ro)
+    got = np.concatenate([b[2].cpu().numpy() for b in batches])
+    assert (got[:, 0] == want["score"]).all() and (got[:, 1] == want["end_query"]).all() and (got[:, 2] == want["end_ref"]).all()
