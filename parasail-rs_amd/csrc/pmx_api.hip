@@ -136,6 +136,43 @@ static void init_builtins()
     g_nuc44.type = PARASAIL_MATRIX_TYPE_SQUARE; g_nuc44.length = 16; g_nuc44.alphabet = pmx_nuc44_alphabet; g_nuc44.query = nullptr;
 }
 
+extern "C" parasail_matrix_t *parasail_matrix_from_file(const char *filename);
+
+// The reference documents 66 built-in names (blosum30..100, pam10..500: src/matrix/mod.rs:46-50); the tables themselves live in
+// the parasail C library, which is not in this image, and typing 64 of them from memory cannot be checked here.  Embedded:
+// blosum62, nuc44 (both verified against files: tests/golden/blosum62.txt, the reference's own tests/square.txt).  Every other
+// name resolves from $PMX_MATRIX_DIR/<name> or <name>.txt (NCBI format, the loader of parasail_matrix_from_file) and then
+// behaves like a built-in: cached for the life of the process, never freed, set_value rejected.
+static const parasail_matrix_t *lookup_in_matrix_dir(const std::string &lname)
+{
+    static std::mutex mx;
+    static std::unordered_map<std::string, const parasail_matrix_t *> cache;
+    for (char c : lname) if (!(isalnum((unsigned char)c) || c == '_' || c == '-' || c == '.')) return nullptr;    // a name, not a path
+    if (lname.empty() || lname[0] == '.') return nullptr;
+    std::lock_guard<std::mutex> lk(mx);
+    auto it = cache.find(lname);
+    if (it != cache.end()) return it->second;
+    const char *dir = getenv("PMX_MATRIX_DIR");
+    if (!dir || !*dir) return nullptr;
+    parasail_matrix_t *m = nullptr;
+    for (const char *suffix : {"", ".txt", ".mat"}) {
+        const std::string path = std::string(dir) + "/" + lname + suffix;
+        m = parasail_matrix_from_file(path.c_str());
+        if (m) break;
+    }
+    if (!m) return nullptr;
+    MatrixBox *b = nullptr;
+    {   // from here on it is a built-in: out of the table of caller-owned matrices, not writable
+        std::lock_guard<std::mutex> lk2(g_mx_mutex);
+        auto bi = g_boxes.find(m);
+        if (bi != g_boxes.end()) { b = bi->second; g_boxes.erase(bi); }
+    }
+    if (b) { b->name = lname; b->m.name = b->name.c_str(); }
+    m->user_matrix = nullptr;
+    cache[lname] = m;
+    return m;
+}
+
 // src/matrix/mod.rs:57-73: NULL -> Error::FailedLookup.  Built-ins are static, never freed.
 extern "C" const parasail_matrix_t *parasail_matrix_lookup(const char *matrixname)
 {
@@ -145,7 +182,7 @@ extern "C" const parasail_matrix_t *parasail_matrix_lookup(const char *matrixnam
     for (auto &c : s) c = (char)tolower((unsigned char)c);
     if (s == "blosum62") return &g_blosum62;
     if (s == "nuc44") return &g_nuc44;
-    return nullptr;
+    return lookup_in_matrix_dir(s);
 }
 
 // File formats: tests/square.txt:1-27 (square, trailing wildcard row/col) and

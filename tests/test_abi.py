@@ -213,3 +213,27 @@ def test_error_paths_without_gpu(pkg):
     assert pkg.lib.pmx_kernel_for(C.byref(cfg), 150, 150) == b"pmx_general_kernel"
     cfg = pkg.pmx_config_t(pkg.MODE_NW, 0, 2, 5, 16, 0, al.matrix.inner)           # open < extend -> general kernel
     assert pkg.lib.pmx_kernel_for(C.byref(cfg), 150, 150) == b"pmx_general_kernel"
+
+
+def test_matrix_lookup_resolves_documented_names_from_a_directory(pkg, tmp_path, monkeypatch):
+    """src/matrix/mod.rs:46-50 documents blosum{30..100} and pam{10..500}; embedded here are blosum62 and nuc44, every other name
+    resolves from $PMX_MATRIX_DIR (NCBI-format files through the loader) and then behaves like a built-in.  The file used is
+    tests/golden/blosum62.txt under other names: the mechanism is what is tested, not table values."""
+    import shutil
+    src = os.path.join(ROOT, "tests", "golden", "blosum62.txt")
+    shutil.copy(src, tmp_path / "blosum50")
+    shutil.copy(src, tmp_path / "pam250.txt")
+    with pytest.raises(pkg.FailedLookup):
+        pkg.Matrix.from_name("blosum50")                      # no directory configured
+    monkeypatch.setenv("PMX_MATRIX_DIR", str(tmp_path))
+    b62 = pkg.Matrix.from_name("blosum62")
+    for name in ("blosum50", "BLOSUM50", "pam250"):
+        m = pkg.Matrix.from_name(name)
+        assert m.size == 24 and (m.to_numpy() == b62.to_numpy()).all()
+        with pytest.raises(pkg.NotBuiltIn):                   # built-in semantics: set_value refused (src/matrix/mod.rs:222-239)
+            m.set_value(0, 0, 5)
+    a, b = pkg.Matrix.from_name("blosum50"), pkg.Matrix.from_name("blosum50")
+    assert C.addressof(a.inner.contents) == C.addressof(b.inner.contents)       # cached: one table per name
+    for bad in ("blosum45", "../blosum50", "/etc/passwd", ""):
+        with pytest.raises((pkg.FailedLookup, pkg.PanicError)):
+            pkg.Matrix.from_name(bad)

@@ -129,3 +129,40 @@ def test_long_pairs_have_no_length_limit(pkg, orc):
     st = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).use_stats().build().align(q3[:300], r3)
     w = orc.align(orc.NW, q3[:300], r3, 5, 2, om, stats=True)
     assert (st.get_score(), st.get_matches(), st.get_length()) == (w.score, w.matches, w.length)
+
+
+def test_ssw_begin_positions_and_packed_cigar(pkg, orc):
+    """SSW emulation (/root/reference/src/aligner/mod.rs:491-529, src/alignment/mod.rs:506-551; KAT tests/test_parasail.rs:738-756 is
+    ACGT vs ACGT only): score, end AND begin coordinates and the packed `len << 4 | op` CIGAR on 520 random / mutated pairs with
+    mismatches and gaps, DNA and protein, against the oracle's local alignment + walk."""
+    import re
+    rng = np.random.default_rng(8600)
+    ops = "MIDNSHP=X"
+    cases = []
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    for t in range(400):
+        q = random_seqs(rng, 1, 8, 180)[0]
+        core = mutate(rng, q[rng.integers(0, len(q) // 2):], 0.12, 0.06)
+        r = random_seqs(rng, 1, 0, 40)[0] + core + random_seqs(rng, 1, 0, 40)[0] if t % 4 else random_seqs(rng, 1, 5, 200)[0]
+        cases.append((q, r, pm, om, 5, 2))
+    pb, ob = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    for t in range(120):
+        q = random_seqs(rng, 1, 10, 150, AA)[0]
+        r = random_seqs(rng, 1, 0, 30, AA)[0] + mutate(rng, q, 0.3, 0.05, AA) + random_seqs(rng, 1, 0, 30, AA)[0]
+        cases.append((q, r, pb, ob, 11, 1))
+    nontrivial = 0
+    for q, r, m, o, go, ge in cases:
+        res = pkg.Aligner.new().matrix(m).gap_open(go).gap_extend(ge).build().ssw(q, r)
+        w = orc.align(orc.SW, q, r, go, ge, o, trace=True)
+        ops_w, bq, br = orc.walk(w)
+        text = orc.cigar(w)
+        assert res.score() == min(max(w.score, 0), 65535)
+        if w.score == 0:
+            continue
+        assert (res.query_end(), res.ref_end()) == (w.end_query, w.end_ref)
+        assert (res.query_start(), res.ref_start()) == (bq, br), (q, r)
+        packed = [(int(n) << 4) | ops.index(c) for n, c in re.findall(r"(\d+)([=XID])", text)]
+        got = [res.cigar()[k] for k in range(res.cigar_len())]
+        assert got == packed, (q, r, got, packed)
+        nontrivial += len(packed) > 2
+    assert nontrivial > 300
