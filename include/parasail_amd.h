@@ -323,6 +323,19 @@ int pmx_align_batch_cigar_device(const pmx_config_t *cfg, int64_t n,
                                  pmx_record_t *d_out, char *d_cigar_text, int64_t cigar_capacity,
                                  int64_t *d_cigar_off, void *stream);
 
+/* Score tables for a batch (extension: the reference returns one table per call, src/alignment/mod.rs:123-192).  All pointers are
+ * device pointers, asynchronous on `stream`.  d_tab_off[k] (n + 1 entries) = cells before pair k's [qlen][rlen] int32 row-major
+ * table in d_score_table; d_score_row (last rows) is packed like the references, d_score_col (last columns) like the queries;
+ * any of the three outputs, and d_out, may be NULL.  4 bytes per cell: this is the one output of the path that is bound by HBM
+ * write bandwidth. */
+int pmx_align_batch_table_device(const pmx_config_t *cfg, int64_t n,
+                                 const uint8_t *d_qbuf, const int64_t *d_qoff,
+                                 const uint8_t *d_rbuf, const int64_t *d_roff,
+                                 int32_t max_qlen, int32_t max_rlen,
+                                 const int64_t *d_tab_off, int32_t *d_score_table,
+                                 int32_t *d_score_row, int32_t *d_score_col,
+                                 pmx_record_t *d_out, void *stream);
+
 /* Multi-GPU (one process driving several GPUs of a node).  Pairs are independent, so the batch is cut into ndev contiguous
  * blocks with about equal numbers of cells (sum of qlen * rlen; pmx_shard_bounds_by_cells is the planner), block g runs on
  * devices[g] from its own persistent host thread, and every block's records land in `out` at its pairs' positions: input order,

@@ -137,6 +137,8 @@ _sig("pmx_align_batch_multi", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_v
 _sig("pmx_align_profile_batch_multi", C.c_int, C.POINTER(pmx_config_t), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
 _sig("pmx_shard_bounds_by_cells", C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+_sig("pmx_align_batch_table_device", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _libc_free = C.CDLL(None).free
 _libc_free.argtypes = [C.c_void_p]
 

@@ -566,7 +566,14 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
     a.score_col = dcol[0].p; a.matches_col = dcol[1].p; a.similar_col = dcol[2].p; a.length_col = dcol[3].p;
     a.trace_table = dtrace.p;
 
-    int rc = pmx_launch_general(a, sp.stats, nullptr);
+    int rc = 1;
+    if ((sp.table || sp.rowcol) && !sp.stats && !sp.trace && sp.band < 0 && !pssm && sp.width != 8 && sp.width != 16)
+        // score table / last row and column: the row-by-row kernel that writes at HBM speed (pmx_table.hip); widths 8 / 16 keep the
+        // general kernel, which reports their saturation
+        rc = pmx_launch_table(sp.mode, sp.sg_flags, open, gap, dm.d, 1, dq.p, doff.p, 0, dr.p, doff.p + 2, s1Len, s2Len,
+                              nullptr, dtab[0].p, drow[0].p, dcol[0].p, drec.p, nullptr);
+    if (rc < 0) die("table kernel launch failed", (hipError_t)(-rc));
+    if (rc == 1) rc = pmx_launch_general(a, sp.stats, nullptr);
     if (rc) die("general kernel launch failed (matrix too large for LDS?)", hipSuccess);
     pmx_record_t rec; pmx_stats_t st = {0, 0, 0};
     HIP_OR_DIE(hipMemcpy(&rec, drec.p, sizeof rec, hipMemcpyDeviceToHost));
@@ -1579,6 +1586,65 @@ extern "C" int pmx_align_batch_banded(const pmx_config_t *cfg, const parasail_pr
     }
     if (rc) return rc;
     HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- score tables for a batch (extension; the reference returns one table per call, src/alignment/mod.rs:123-192) ----------
+// d_tab_off[k] = number of cells before pair k's [qlen][rlen] int32 table in d_score_table (n + 1 entries); d_score_row is packed
+// like the references (roff), d_score_col like the queries (qoff); any of the three outputs may be NULL.
+extern "C" int pmx_align_batch_table_device(const pmx_config_t *cfg, int64_t n,
+                                            const uint8_t *d_qbuf, const int64_t *d_qoff,
+                                            const uint8_t *d_rbuf, const int64_t *d_roff,
+                                            int32_t max_qlen, int32_t max_rlen,
+                                            const int64_t *d_tab_off, int32_t *d_score_table,
+                                            int32_t *d_score_row, int32_t *d_score_col,
+                                            pmx_record_t *d_out, void *stream)
+{
+    if (check_cfg(cfg)) return -1;
+    if (n <= 0) return 0;
+    if (!d_qbuf || !d_qoff || !d_rbuf || !d_roff) { set_err("null buffer"); return -1; }
+    if (d_score_table && !d_tab_off) { set_err("a score table needs d_tab_off"); return -1; }
+    if (max_qlen <= 0 || max_rlen <= 0) { set_err("max_qlen / max_rlen must be positive"); return -1; }
+    if (cfg->want & ~PMX_WANT_SORTED) { set_err("table batches return score tables, rows / columns and records"); return -1; }
+    if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
+    DevMat dm;
+    if (get_devmat(cfg->matrix, &dm)) return -1;
+    StreamGuard guard(stream);
+    if (!guard.ok) { set_err("stream guard failed"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = pmx_launch_table(cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, dm.d, n, d_qbuf, d_qoff, 0, d_rbuf, d_roff,
+                              max_qlen, max_rlen, d_tab_off, d_score_table, d_score_row, d_score_col, d_out, st);
+    if (rc < 0) { set_err("table kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
+    if (rc == 0) { g_last_kernel = "pmx_table_kernel"; return 0; }
+    // outside the row-by-row kernel's window (references beyond 1 024 symbols, open < extend, ...): the general kernel, in chunks
+    const size_t stride = (size_t)8 * max_rlen;
+    const bool fits = pmx_general_lds_fits(dm.d.msize, dm.d.msize, max_rlen);
+    const size_t rs_stride = fits ? 0 : (((size_t)max_rlen + 8 + 15) & ~(size_t)15);
+    const size_t per_pair = stride * sizeof(int32_t) + rs_stride;
+    int64_t chunk = (int64_t)(2e9 / (double)per_pair);
+    if (chunk < 1) chunk = 1;
+    if (chunk > n) chunk = n;
+    void *bound = nullptr;
+    if (scratch_reserve((size_t)chunk * per_pair, &bound)) return -1;
+    DevBuf<pmx_record_t> tmp_rec;
+    if (!d_out && tmp_rec.try_alloc((size_t)n)) { set_err("out of device memory"); return -2; }
+    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+        const int64_t m = (n - c0 < chunk) ? n - c0 : chunk;
+        PmxGeneralArgs a; memset(&a, 0, sizeof a);
+        a.qbuf = d_qbuf; a.qoff = d_qoff + c0; a.rbuf = d_rbuf; a.roff = d_roff + c0; a.n = m; a.max_rlen = max_rlen;
+        a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize;
+        a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend; a.band = -1; a.bits = 32;
+        a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
+        if (!fits) { a.rs_scratch = (uint8_t *)bound + (size_t)chunk * stride * sizeof(int32_t); a.rs_stride = (long long)rs_stride; }
+        a.rec = (d_out ? d_out : tmp_rec.p) + c0;
+        a.tab_off = d_tab_off ? d_tab_off + c0 : nullptr; a.score_table = d_score_table;
+        a.score_row = d_score_row; a.score_col = d_score_col;
+        if (m == 1 && n > 1) { set_err("general-kernel table batches need chunks of at least two pairs"); return -1; }
+        rc = pmx_launch_general(a, false, st);
+        if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
+    }
+    if (!d_out) HIP_OR_RET(hipStreamSynchronize(st));
+    g_last_kernel = "pmx_general_kernel/tables";
     return 0;
 }
 
