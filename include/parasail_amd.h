@@ -20,6 +20,7 @@
 #ifndef PARASAIL_AMD_H
 #define PARASAIL_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -349,6 +350,10 @@ int pmx_align_profile_batch_multi(const pmx_config_t *cfg, const parasail_profil
                                   const int *devices, int ndev, pmx_record_t *out, pmx_stats_t *stats_out);
 /* bounds[0..parts]: block g = pairs [bounds[g], bounds[g+1]).  qoff == NULL: one shared query.  Pure host arithmetic. */
 int pmx_shard_bounds_by_cells(int64_t n, const int64_t *qoff, const int64_t *roff, int parts, int64_t *bounds);
+
+/* Optional: page-lock caller-owned host buffers once, so the host-buffer entries above move them at full PCIe rate. */
+int pmx_host_register(void *p, size_t bytes);
+int pmx_host_unregister(void *p);
 
 /* Runtime. */
 int pmx_device_count(void);

@@ -55,8 +55,9 @@ enum {
  * vertical move, consumes a query character).  SAM convention with
  * query = s1, reference = s2: consuming only the reference is 'D',
  * consuming only the query is 'I'. */
-#define ORC_CIGAR_FOR_INS_STATE 'D'
-#define ORC_CIGAR_FOR_DEL_STATE 'I'
+#include "../include/pmx_conventions.h"
+#define ORC_CIGAR_FOR_INS_STATE PMX_CIGAR_LETTER_FOR_INS_STATE
+#define ORC_CIGAR_FOR_DEL_STATE PMX_CIGAR_LETTER_FOR_DEL_STATE
 
 typedef struct {
     int score, end_query, end_ref;

@@ -139,6 +139,8 @@ _sig("pmx_align_profile_batch_multi", C.c_int, C.POINTER(pmx_config_t), C.c_void
 _sig("pmx_shard_bounds_by_cells", C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 _sig("pmx_align_batch_table_device", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("pmx_host_register", C.c_int, C.c_void_p, C.c_size_t)
+_sig("pmx_host_unregister", C.c_int, C.c_void_p)
 _libc_free = C.CDLL(None).free
 _libc_free.argtypes = [C.c_void_p]
 
@@ -881,6 +883,18 @@ def align_profile_batch_device(cfg, profile, n, d_rbuf, d_roff, max_rlen, d_out,
     rc = lib.pmx_align_profile_batch_device(C.byref(cfg), profile.inner, n, d_rbuf, d_roff, max_rlen, d_out, d_stats, stream)
     if rc:
         raise BatchError(lib.pmx_last_error().decode())
+
+
+def host_register(*arrays):
+    """Page-lock numpy arrays handed to the host-buffer batch entries (full PCIe rate); undo with host_unregister."""
+    for a in arrays:
+        if lib.pmx_host_register(a.ctypes.data, a.nbytes):
+            raise BatchError(lib.pmx_last_error().decode())
+
+
+def host_unregister(*arrays):
+    for a in arrays:
+        lib.pmx_host_unregister(a.ctypes.data)
 
 
 def shard_bounds_by_cells(qoff, roff, parts):

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/parasail_amd.h"
+#include "../../include/pmx_conventions.h"
 
 #define PMX_MAX_FAST_MSIZE 32      // fast kernels stage the matrix in LDS as int16[msize*msize]
 

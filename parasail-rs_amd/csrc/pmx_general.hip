@@ -357,8 +357,8 @@ int pmx_launch_general(const PmxGeneralArgs &a_in, bool want_stats, hipStream_t 
 #define OP_X 8u
 // state INS (E, consumes a reference character) prints 'D'; state DEL (F, consumes a query
 // character) prints 'I' (SAM sense with query = s1, reference = s2).
-#define OP_FOR_INS_STATE OP_D
-#define OP_FOR_DEL_STATE OP_I
+#define OP_FOR_INS_STATE PMX_BAM_OP_FOR_INS_STATE    // include/pmx_conventions.h
+#define OP_FOR_DEL_STATE PMX_BAM_OP_FOR_DEL_STATE    // include/pmx_conventions.h
 
 __global__ void pmx_walk_kernel(const PmxWalkArgs a)
 {

@@ -29,8 +29,8 @@
 #define OP_D 2u
 #define OP_EQ 7u
 #define OP_X 8u
-#define OP_FOR_INS_STATE OP_D    // E / horizontal / consumes a reference character
-#define OP_FOR_DEL_STATE OP_I    // F / vertical   / consumes a query character
+#define OP_FOR_INS_STATE PMX_BAM_OP_FOR_INS_STATE    // include/pmx_conventions.h
+#define OP_FOR_DEL_STATE PMX_BAM_OP_FOR_DEL_STATE    // include/pmx_conventions.h
 
 __device__ __forceinline__ unsigned a16(unsigned a, unsigned b) { unsigned r; asm("v_add_u16_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ unsigned s16(unsigned a, unsigned b) { unsigned r; asm("v_sub_u16_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }

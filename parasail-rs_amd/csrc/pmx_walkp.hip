@@ -22,8 +22,8 @@
 #define OP_D 2u
 #define OP_EQ 7u
 #define OP_X 8u
-#define OP_FOR_INS_STATE OP_D    // E / horizontal / consumes a reference character   [UNPINNED letters, see DESIGN.md]
-#define OP_FOR_DEL_STATE OP_I    // F / vertical   / consumes a query character
+#define OP_FOR_INS_STATE PMX_BAM_OP_FOR_INS_STATE    // include/pmx_conventions.h
+#define OP_FOR_DEL_STATE PMX_BAM_OP_FOR_DEL_STATE    // include/pmx_conventions.h
 
 #define LG 8                     // lanes per pair
 
