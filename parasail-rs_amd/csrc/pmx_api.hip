@@ -1728,7 +1728,7 @@ static int cigar_device_run(const pmx_config_t *cfg, const DevMat &dm, int64_t n
     if (rc) { set_err("text offset scan failed (%d)", rc); return rc; }
     rc = pmx_launch_cigar_render_slots(dops, d_qoff, d_roff, ops_base, nops, d_text_off, d_text, capacity, n, st);
     if (rc) { set_err("cigar render launch failed (%d)", rc); return rc; }
-    g_last_kernel = variant >= 20 ? "pmx_sw16_kernel/packed trace + pmx_walk16_kernel" : "pmx_nwsg16v_kernel/packed trace + pmx_walk16_kernel";
+    g_last_kernel = variant >= 20 ? "pmx_sw16_kernel/packed trace + pmx_walkp_kernel" : "pmx_nwsg16v_kernel/packed trace + pmx_walkp_kernel";
     return 0;
 }
 
@@ -1815,7 +1815,7 @@ static int cigar_chunk(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
         if (scratch_reserve(tbytes, (void **)&tbuf, SCR_TRACE)) return -1;
         rc = pmx_launch_trace16(variant, b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, drec.p, tbuf, Tmax,
                                 dops, doo.p, dnops.p, dbeg.p, nullptr);
-        g_last_kernel = variant >= 20 ? "pmx_sw16_kernel/packed trace + pmx_walk16_kernel" : variant >= 10 ? "pmx_nwsg16v_kernel/packed trace + pmx_walk16_kernel" : "pmx_trace16_kernel + pmx_walk16_kernel";
+        g_last_kernel = variant >= 20 ? "pmx_sw16_kernel/packed trace + pmx_walkp_kernel" : variant >= 10 ? "pmx_nwsg16v_kernel/packed trace + pmx_walkp_kernel" : "pmx_trace16_kernel + pmx_walk16_kernel";
         if (rc) { set_err("trace16 launch failed (%d)", rc); return rc < 0 ? rc : -1; }
     } else {
         std::vector<int64_t> tab_off(n + 1);
