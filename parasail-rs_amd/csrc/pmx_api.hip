@@ -1107,20 +1107,23 @@ static int general_batch(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
 // tie-breaks as the traceback bits): the shared-profile sweep writes the packed 4-bit records (14.75 instructions per two
 // cells against 34 for the kernel that carries nine statistics planes) and the walk counts along the path.  Chunks bound
 // the trace scratch; the walk of chunk c runs beside the sweep of chunk c + 1 on a second stream.
-struct TraceWs { hipStream_t walk = nullptr; hipEvent_t sweep_done[2] = {nullptr, nullptr}, walk_done[2] = {nullptr, nullptr}; int dev = -1; };
+struct TraceWs { hipStream_t walk = nullptr, aux = nullptr; hipEvent_t sweep_done[2] = {nullptr, nullptr}, walk_done[2] = {nullptr, nullptr}, start = nullptr; int dev = -1; };
 static thread_local TraceWs g_tws;
 static int trace_ws_init()
 {
     int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
     if (g_tws.dev == dev) return 0;
-    if (g_tws.walk) {
-        (void)hipStreamDestroy(g_tws.walk);
+    if (g_tws.walk) {                                   // the thread moved to another device: release the old device's objects
+        (void)hipStreamDestroy(g_tws.walk); (void)hipStreamDestroy(g_tws.aux); (void)hipEventDestroy(g_tws.start);
         for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(g_tws.sweep_done[k]); (void)hipEventDestroy(g_tws.walk_done[k]); }
         g_tws = TraceWs();
     }
+    // the walk gets the higher priority: its few, latency-bound workgroups slip in between the sweep's as those retire
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     HIP_OR_RET(hipStreamCreateWithPriority(&g_tws.walk, hipStreamNonBlocking, prio_hi));
+    HIP_OR_RET(hipStreamCreateWithFlags(&g_tws.aux, hipStreamNonBlocking));
+    HIP_OR_RET(hipEventCreateWithFlags(&g_tws.start, hipEventDisableTiming));
     for (int k = 0; k < 2; ++k) {
         HIP_OR_RET(hipEventCreateWithFlags(&g_tws.sweep_done[k], hipEventDisableTiming));
         HIP_OR_RET(hipEventCreateWithFlags(&g_tws.walk_done[k], hipEventDisableTiming));
@@ -1159,6 +1162,9 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
     const bool sg = cfg->mode == PMX_MODE_SG;
     const int col_pen = !(sg && (cfg->sg_flags & PMX_SG_QB)), row_pen = !(sg && (cfg->sg_flags & PMX_SG_DB));
     const int gsel = G == 16 ? 1 : G == 32 ? 2 : 3;
+    // Sweeps of consecutive chunks go to two streams in turn (the caller's and an internal one): a chunk is a few thousand equally
+    // long waves, so the tail of chunk c's launch is backfilled by chunk c + 1's workgroups instead of idling the chip.
+    if (two) { HIP_OR_RET(hipEventRecord(g_tws.start, st)); HIP_OR_RET(hipStreamWaitEvent(g_tws.aux, g_tws.start, 0)); }
     int idx = 0;
     for (long long c0 = 0; c0 < b.n; c0 += chunk, ++idx) {
         PmxBatch bk = b;
@@ -1167,12 +1173,13 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
         if (b.perm) bk.perm = b.perm + c0;                    // positions c0 .. of the processing order; records stay indexed by pair
         else { bk.roff = b.roff + c0; out_k = d_out + c0; st_k = d_stats + c0; }
         uint32_t *tb = (uint32_t *)((unsigned char *)tbuf + (two ? (size_t)(idx & 1) * cbytes : 0));
-        if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(st, g_tws.walk_done[idx & 1], 0));
-        int rc = pmx_launch_nwsgq_trace(variant, bk, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, out_k, tb, Tmax, st);
+        const hipStream_t sws = (two && (idx & 1)) ? g_tws.aux : st;
+        if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(sws, g_tws.walk_done[idx & 1], 0));    // this buffer's previous walk is done
+        int rc = pmx_launch_nwsgq_trace(variant, bk, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, out_k, tb, Tmax, sws);
         if (rc) { set_err("shared-profile traceback sweep failed (%d)", rc); return rc < 0 ? rc : -1; }
         hipStream_t ws = st;
         if (two) {
-            HIP_OR_RET(hipEventRecord(g_tws.sweep_done[idx & 1], st));
+            HIP_OR_RET(hipEventRecord(g_tws.sweep_done[idx & 1], sws));
             HIP_OR_RET(hipStreamWaitEvent(g_tws.walk, g_tws.sweep_done[idx & 1], 0));
             ws = g_tws.walk;
         }
@@ -1652,29 +1659,6 @@ extern "C" int pmx_align_batch_table_device(const pmx_config_t *cfg, int64_t n,
 // Sweep (packed 4-bit traceback to HBM scratch) and walk run in chunks on two streams: the walk of chunk c (latency-bound, one
 // lane per pair) runs beside the sweep of chunk c + 1 (VALU-bound); the trace scratch is double-buffered.  The walk leaves
 // run-length ops in per-pair slots and each pair's text length; one scan and one render finish the batch on the caller's stream.
-struct CigarWs { hipStream_t walk = nullptr; hipEvent_t sweep_done[2] = {nullptr, nullptr}, walk_done[2] = {nullptr, nullptr}; int dev = -1; };
-static thread_local CigarWs g_cig;
-static int cigar_ws_init()
-{
-    int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
-    if (g_cig.dev == dev) return 0;
-    if (g_cig.walk) {                                   // the thread moved to another device: release the old device's objects
-        (void)hipStreamDestroy(g_cig.walk);
-        for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(g_cig.sweep_done[k]); (void)hipEventDestroy(g_cig.walk_done[k]); }
-        g_cig = CigarWs();
-    }
-    // the walk gets the higher priority: its few, latency-bound workgroups slip in between the sweep's as those retire
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    HIP_OR_RET(hipStreamCreateWithPriority(&g_cig.walk, hipStreamNonBlocking, prio_hi));
-    for (int k = 0; k < 2; ++k) {
-        HIP_OR_RET(hipEventCreateWithFlags(&g_cig.sweep_done[k], hipEventDisableTiming));
-        HIP_OR_RET(hipEventCreateWithFlags(&g_cig.walk_done[k], hipEventDisableTiming));
-    }
-    g_cig.dev = dev;
-    return 0;
-}
-
 // 0 done (asynchronously on `st`), 1 not eligible for the packed traceback sweeps, <0 error.
 // The offset arrays are absolute into d_qbuf / d_rbuf; ops_base = qoff[0] + roff[0] (0 when the offsets start at 0).
 static int cigar_device_run(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
@@ -1686,7 +1670,7 @@ static int cigar_device_run(const pmx_config_t *cfg, const DevMat &dm, int64_t n
     PmxBatch b = {d_qbuf, d_qoff, d_rbuf, d_roff, n, mq, mr, 0, nullptr, nullptr, nullptr, 0, 0};
     int variant = 0, Tmax = 0; size_t tbytes = 0;
     if (pmx_trace16_plan(b, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes) != 0 || variant < 10) return 1;
-    if (cigar_ws_init()) return -1;
+    if (trace_ws_init()) return -1;
     // chunks: at most ~3 GB of trace each (two buffers), at least two for the overlap once the batch is worth it
     double chunk_bytes = 3e9;
     if (const char *e = getenv("PMX_CIGAR_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
@@ -1707,23 +1691,24 @@ static int cigar_device_run(const pmx_config_t *cfg, const DevMat &dm, int64_t n
         scratch_reserve(misc_bytes, (void **)&misc, SCR_CIG)) return -1;
     int32_t *nops = (int32_t *)misc, *beg = nops + n, *textlen = beg + 2 * n;
     void *scan_tmp = (void *)(((uintptr_t)(textlen + n + 2) + 255) & ~(uintptr_t)255);
+    // sweeps of consecutive chunks alternate between the caller's stream and an internal one (the tail of one launch is
+    // backfilled by the next); every walk runs on the high-priority walk stream after its sweep
+    if (two) { HIP_OR_RET(hipEventRecord(g_tws.start, st)); HIP_OR_RET(hipStreamWaitEvent(g_tws.aux, g_tws.start, 0)); }
     int idx = 0;
     for (int64_t c0 = 0; c0 < n; c0 += chunk, ++idx) {
         PmxBatch bk = b;
         bk.n = (n - c0 < chunk) ? n - c0 : chunk;
         bk.qoff = d_qoff + c0; bk.roff = d_roff + c0;
-        if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(st, g_cig.walk_done[idx & 1], 0));     // this trace buffer's last walk is done
-        PmxWalkSplit sp = {two ? g_cig.walk : st, g_cig.sweep_done[idx & 1], two ? g_cig.walk_done[idx & 1] : nullptr,
+        const hipStream_t sws = (two && (idx & 1)) ? g_tws.aux : st;
+        if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(sws, g_tws.walk_done[idx & 1], 0));     // this trace buffer's last walk is done
+        PmxWalkSplit sp = {two ? g_tws.walk : st, g_tws.sweep_done[idx & 1], two ? g_tws.walk_done[idx & 1] : nullptr,
                            ops_base - c0, textlen + c0};
         const int rc = pmx_launch_trace16(variant, bk, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out + c0,
                                           (uint32_t *)((unsigned char *)tbuf + (two ? (size_t)(idx & 1) * cbytes : 0)), Tmax,
-                                          dops, nullptr, nops + c0, beg + 2 * c0, st, nullptr, &sp);
+                                          dops, nullptr, nops + c0, beg + 2 * c0, sws, nullptr, &sp);
         if (rc) { set_err("traceback launch failed (%d)", rc); return rc < 0 ? rc : -1; }
     }
-    if (two) {
-        HIP_OR_RET(hipStreamWaitEvent(st, g_cig.walk_done[(idx - 1) & 1], 0));
-        if (idx >= 2) HIP_OR_RET(hipStreamWaitEvent(st, g_cig.walk_done[idx & 1], 0));
-    }
+    if (two) HIP_OR_RET(hipStreamWaitEvent(st, g_tws.walk_done[(idx - 1) & 1], 0));      // the walk stream is in order: the last walk covers all
     int rc = pmx_launch_text_offsets(textlen, n, d_text_off, scan_tmp, scan_bytes, st);
     if (rc) { set_err("text offset scan failed (%d)", rc); return rc; }
     rc = pmx_launch_cigar_render_slots(dops, d_qoff, d_roff, ops_base, nops, d_text_off, d_text, capacity, n, st);

@@ -5,9 +5,9 @@
 # (profiles/<tag>/cfgN_pmc_summary.json, cfgN_kernel_stats.csv).
 TAG=${1:-r02}
 mkdir -p /root/repo/profiles/$TAG
-for spec in "2 pmx_sw16_kernel" "3 pmx_nwsg16q_kernel" "4 pmx_nwsg16v_kernel" "5 pmx_sw16_kernel"; do
-    set -- $spec
-    bash /root/repo/profiles/run_profile.sh $TAG $1 $2 > /root/repo/gpurun_out/collect_${TAG}_cfg$1.log 2>&1
+for spec in "2 pmx_sw16_kernel<8,_19,_6>" "3 pmx_nwsg16q_kernel" "4 pmx_nwsg16v_kernel" "5 pmx_sw16_kernel<64,_16,_6>"; do
+    set -- $spec; set -- $1 "${2//_/ }"
+    bash /root/repo/profiles/run_profile.sh $TAG $1 "$2" > /root/repo/gpurun_out/collect_${TAG}_cfg$1.log 2>&1
     OUT=/root/repo/gpurun_out/prof_${TAG}_cfg$1
     cp $OUT/cfg$1_pmc_summary.json $OUT/cfg$1_kernel_stats.csv /root/repo/profiles/$TAG/ 2>/dev/null
     if [ "$1" = "4" ]; then python3 /root/repo/profiles/summarize_pmc.py $OUT pmx_walkp_kernel /root/repo/profiles/$TAG/cfg4_walk_pmc_summary.json; fi
