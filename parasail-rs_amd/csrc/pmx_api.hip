@@ -1141,7 +1141,7 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
     if (pmx_nwsgq_trace_plan(b, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes, &G, &R) != 0) return 1;
     if (trace_ws_init()) return -1;
     const long long NP = 2 * (64 / G) * 4;                     // pairs per workgroup of the sweep
-    double chunk_bytes = 16e9;
+    double chunk_bytes = 40e9;                                 // (measured on cfg 3: 8 GB chunks 55.0 ms, 24 GB 53.1 ms, 40 GB 51.0 ms)
     { size_t fb = 0, tb = 0; if (hipMemGetInfo(&fb, &tb) == hipSuccess && 0.2 * (double)fb < chunk_bytes) chunk_bytes = 0.2 * (double)fb; }
     if (const char *e = getenv("PMX_STATS_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
     const double per_pair = (double)tbytes / (double)b.n;
@@ -1671,8 +1671,10 @@ static int cigar_device_run(const pmx_config_t *cfg, const DevMat &dm, int64_t n
     int variant = 0, Tmax = 0; size_t tbytes = 0;
     if (pmx_trace16_plan(b, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes) != 0 || variant < 10) return 1;
     if (trace_ws_init()) return -1;
-    // chunks: at most ~3 GB of trace each (two buffers), at least two for the overlap once the batch is worth it
-    double chunk_bytes = 3e9;
+    // chunks: at most ~12 GB of trace each (two buffers; measured on 1.25 M pairs of 250 x 250: 3 GB chunks 27.8 ms, 12 GB 26.2 ms --
+    // fewer launch tails), at most 15 % of the free HBM each, at least two for the overlap once the batch is worth it
+    double chunk_bytes = 12e9;
+    { size_t fb = 0, tb = 0; if (hipMemGetInfo(&fb, &tb) == hipSuccess && 0.15 * (double)fb < chunk_bytes) chunk_bytes = 0.15 * (double)fb; }
     if (const char *e = getenv("PMX_CIGAR_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
     int64_t nchunks = (int64_t)((double)tbytes / chunk_bytes) + 1;
     if (nchunks < 2 && n >= 16384) nchunks = 2;

@@ -1434,7 +1434,8 @@ int pmx_launch_nwsgv_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m
     case 6: return launch_nwsgm<32, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 7: return launch_nwsgm<64, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 0: return launch_nwsgv<8, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
-    case 1: return launch_nwsgv<16, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 1: if (getenv("PMX_TRACE_FETCH")) return launch_nwsgv<16, 16, true, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+            return launch_nwsgv<16, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 2: return launch_nwsgv<32, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 3: return launch_nwsgv<64, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     }
