@@ -52,7 +52,8 @@ void pmx_table_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char t_lds[];
     int16_t *mat = reinterpret_cast<int16_t *>(t_lds);                 // transposed: mat[r * msize + q]
-    unsigned char *qs = t_lds + (((size_t)msize * msize * 2 + 15) & ~(size_t)15);   // mapped query symbols
+    unsigned char *rowstage = t_lds + (((size_t)msize * msize * 2 + 15) & ~(size_t)15);          // C > 4: one row of the table, 256 C bytes
+    unsigned char *qs = rowstage + (C > 4 ? 256 * C : 0);                                       // mapped query symbols
     const int lane = threadIdx.x;
     const long long pair = blockIdx.x;
     const long long qb = q_shared ? 0 : qoff[pair], rb = roff[pair];
@@ -120,14 +121,34 @@ void pmx_table_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
             if (sw && h > rowmax && j0 + c < rl) { rowmax = h; rowj = j0 + c; }
         }
         // ---- outputs of the row ----
-        if (tab) {
+        if (tab && C == 4) {                                        // one 16-byte store per lane: 1 KB contiguous per wave and row
             int32_t *dst = tab + (long long)i * rl + j0;
+            if (j0 + 3 < rl) { int4 v = {Hp[0], Hp[1], Hp[2], Hp[3]}; *reinterpret_cast<int4 *>(dst) = v; }
+            else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) if (j0 + x < rl) dst[x] = Hp[x];
+            }
+        }
+        if (tab && C > 4) {
+            // C / 4 stores per lane would each touch every other cache line of the row (lane stride 4 C bytes): the row is turned in LDS
+            // first, so that store x of lane l carries columns 256 x + 4 l .. + 3 -- every store is 1 KB contiguous
+            int4 *stg = reinterpret_cast<int4 *>(rowstage);
 #pragma unroll
             for (int c = 0; c < C; c += 4) {
-                if (j0 + c + 3 < rl) { int4 v = {Hp[c], Hp[c + 1], Hp[c + 2], Hp[c + 3]}; *reinterpret_cast<int4 *>(dst + c) = v; }
-                else {
+                const int4 v = {Hp[c], Hp[c + 1], Hp[c + 2], Hp[c + 3]};
+                const int slot16 = lane * (C / 4) + c / 4;               // 16-byte slot = 4 consecutive columns of the row
+                stg[slot16 ^ ((slot16 >> 3) & 7)] = v;                    // (swizzled: the lanes' writes spread over the banks)
+            }
+            int32_t *dst = tab + (long long)i * rl;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) if (j0 + c + x < rl) dst[c + x] = Hp[c + x];
+            for (int x = 0; x < C / 4; ++x) {
+                const int slot16 = x * 64 + lane, col = slot16 * 4;
+                const int4 v = stg[slot16 ^ ((slot16 >> 3) & 7)];
+                if (col + 3 < rl) *reinterpret_cast<int4 *>(dst + col) = v;
+                else {
+                    if (col < rl) dst[col] = v.x;
+                    if (col + 1 < rl) dst[col + 1] = v.y;
+                    if (col + 2 < rl) dst[col + 2] = v.z;
                 }
             }
         }
@@ -192,7 +213,7 @@ int pmx_launch_table(int mode, int sg_flags, int open, int ext, const PmxDevMatr
     if (getenv("PMX_NO_FAST_TABLE")) return 1;
     if (open < ext || ext < 0 || m.msize > PMX_MAX_FAST_MSIZE || max_rlen > 64 * 16 || max_qlen > 100000) return 1;
     if (!tab_off && n > 1 && table) return 1;
-    const size_t lds = (((size_t)m.msize * m.msize * 2 + 15) & ~(size_t)15) + (size_t)max_qlen + 16;
+    const size_t lds = (((size_t)m.msize * m.msize * 2 + 15) & ~(size_t)15) + (size_t)max_qlen + 16 + (max_rlen > 256 ? 4096 : 0);
     if (lds > 150 * 1024) return 1;
 #define LT(CC) do { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_table_kernel<CC>)); if (rc) return rc; \
                hipLaunchKernelGGL((pmx_table_kernel<CC>), dim3((unsigned)n), dim3(64), lds, stream, qbuf, qoff, q_shared, rbuf, roff, n, \
