@@ -202,6 +202,16 @@ class Cfg2(Workload):
                              "entry": "pmx_align_batch, host buffers page-locked by the caller (pmx_host_register)"}
         finally:
             self.pkg.host_unregister(*self.h)
+        # 2-bit packed input form (a quarter of the sequence bytes over PCIe, spelled out on the device)
+        q2, r2 = self.pkg.pack_2bit(self.h[0]), self.pkg.pack_2bit(self.h[2])
+        ref = al.align_batch_packed(*self.h)
+        got = al.align_batch_2bit(q2, self.h[1], r2, self.h[3])
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); al.align_batch_2bit(q2, self.h[1], r2, self.h[3]); ts.append(time.perf_counter() - t0)
+        res["packed_2bit"] = {"value": round(self.cells / min(ts) / 1e9, 1), "unit": "GCUPS", "ms": round(min(ts) * 1e3, 3),
+                              "entry": "pmx_align_batch_2bit (2 bits per base in pageable host buffers, host records out)",
+                              "identical_records": bool((got == ref).all())}
         return res
 
     def cpu_baseline(self, last_out):

@@ -262,6 +262,14 @@ int pmx_align_batch(const pmx_config_t *cfg, int64_t n,
                     const uint8_t *rbuf, const int64_t *roff,
                     pmx_record_t *out, pmx_stats_t *stats_out /* NULL unless WANT_STATS */);
 
+/* The same with 2-bit packed sequences (additive input form for 4-letter alphabets): base b of a buffer sits in byte b / 4 at
+ * bits 2 (b % 4) and holds the index of its letter in the matrix alphabet (0..3); the offsets count BASES.  A quarter of the
+ * bytes cross PCIe; a small kernel spells the letters out on the device before the usual path runs. */
+int pmx_align_batch_2bit(const pmx_config_t *cfg, int64_t n,
+                         const uint8_t *q2, const int64_t *qoff,
+                         const uint8_t *r2, const int64_t *roff,
+                         pmx_record_t *out, pmx_stats_t *stats_out);
+
 /* Device-resident buffers (all pointers are device pointers on the current device),
  * asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
  * Internal scratch (length-sort permutation, retry list of the perm-table kernel) belongs to the calling

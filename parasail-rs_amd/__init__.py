@@ -141,6 +141,8 @@ _sig("pmx_align_batch_table_device", C.c_int, C.POINTER(pmx_config_t), C.c_int64
      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("pmx_host_register", C.c_int, C.c_void_p, C.c_size_t)
 _sig("pmx_host_unregister", C.c_int, C.c_void_p)
+_sig("pmx_align_batch_2bit", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+     C.c_void_p, C.c_void_p, C.c_void_p)
 _libc_free = C.CDLL(None).free
 _libc_free.argtypes = [C.c_void_p]
 
@@ -763,6 +765,18 @@ class Aligner:
             raise BatchError(lib.pmx_last_error().decode())
         return (out, stats) if stats is not None else out
 
+    def align_batch_2bit(self, q2, qoff, r2, roff):
+        """2-bit packed input (see pack_2bit): offsets count bases."""
+        n = len(roff) - 1
+        cfg = self._config()
+        out = np.zeros(n, dtype=RECORD_DTYPE)
+        stats = np.zeros(n, dtype=STATS_DTYPE) if cfg.want & WANT_STATS else None
+        rc = lib.pmx_align_batch_2bit(C.byref(cfg), n, q2.ctypes.data, qoff.ctypes.data, r2.ctypes.data, roff.ctypes.data,
+                                      out.ctypes.data, stats.ctypes.data if stats is not None else None)
+        if rc:
+            raise BatchError(lib.pmx_last_error().decode())
+        return (out, stats) if stats is not None else out
+
     def align_batch_multi(self, qbuf, qoff, rbuf, roff, devices):
         """One batch across several GPUs of the node (cell-balanced contiguous blocks, records in input order)."""
         n = len(roff) - 1
@@ -883,6 +897,19 @@ def align_profile_batch_device(cfg, profile, n, d_rbuf, d_roff, max_rlen, d_out,
     rc = lib.pmx_align_profile_batch_device(C.byref(cfg), profile.inner, n, d_rbuf, d_roff, max_rlen, d_out, d_stats, stream)
     if rc:
         raise BatchError(lib.pmx_last_error().decode())
+
+
+def pack_2bit(buf, alphabet=b"ACGT"):
+    """ASCII letters -> 2 bits per base (base b in byte b / 4 at bits 2 (b % 4)), the input form of pmx_align_batch_2bit."""
+    lut = np.zeros(256, dtype=np.uint8)
+    for i, ch in enumerate(alphabet[:4]):
+        lut[ch] = i; lut[ord(chr(ch).lower())] = i
+    codes = lut[buf]
+    pad = (-len(codes)) % 4
+    if pad:
+        codes = np.concatenate([codes, np.zeros(pad, dtype=np.uint8)])
+    c = codes.reshape(-1, 4)
+    return (c[:, 0] | (c[:, 1] << 2) | (c[:, 2] << 4) | (c[:, 3] << 6)).astype(np.uint8)
 
 
 def host_register(*arrays):

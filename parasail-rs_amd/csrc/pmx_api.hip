@@ -1042,7 +1042,8 @@ enum { SCR_BOUND = 0, SCR_TRACE = 1, SCR_OPS = 2, SCR_SORT = 3, SCR_RETRY = 4,
        SCR_HQ = 5, SCR_HR = 6, SCR_HQO = 7, SCR_HRO = 8, SCR_HREC = 9, SCR_HST = 10,      // staging of the host-buffer batch entry
        SCR_CIG = 11,                                                                     // device CIGAR entry: counts, begins, text lengths, scan scratch
        SCR_HTEXT = 12, SCR_HTOFF = 13,                                                   // staging of the host CIGAR entry
-       SCR_SLOTS = 14 };
+       SCR_HQ2 = 14, SCR_HR2 = 15,                                                       // 2-bit packed input as it arrived
+       SCR_SLOTS = 16 };
 static thread_local Scratch g_scratch_pool[SCR_SLOTS];
 static int scratch_reserve(size_t bytes, void **out, int slot = SCR_BOUND)
 {
@@ -1396,10 +1397,12 @@ static pmx_config_t with_sort_hint(const pmx_config_t *cfg, int32_t min_rlen, in
     return c;
 }
 
-extern "C" int pmx_align_batch(const pmx_config_t *cfg, int64_t n,
-                               const uint8_t *qbuf, const int64_t *qoff,
-                               const uint8_t *rbuf, const int64_t *roff,
-                               pmx_record_t *out, pmx_stats_t *stats_out)
+// Host buffers in, host records out.  packed2: the sequence buffers hold 2 bits per base (base b in byte b / 4 at bits 2 (b % 4),
+// code c = letter c of the matrix alphabet) and the offsets count bases: a quarter of the bytes cross PCIe and a small kernel
+// spells them out into the staging buffers before the slice is aligned.
+static int host_batch(const pmx_config_t *cfg, int64_t n,
+                      const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
+                      pmx_record_t *out, pmx_stats_t *stats_out, bool packed2)
 {
     if (check_cfg(cfg)) return -1;
     if (n <= 0) return 0;
@@ -1411,56 +1414,89 @@ extern "C" int pmx_align_batch(const pmx_config_t *cfg, int64_t n,
     cfg = &cfg_s;
     const size_t qbytes = (size_t)(qoff[n] - qoff[0]), rbytes = (size_t)(roff[n] - roff[0]);
     if (qoff[0] != 0 || roff[0] != 0) { set_err("offset arrays must start at 0"); return -1; }
+    uint32_t letters = 0;
+    if (packed2) {
+        const char *al = cfg->matrix->alphabet;
+        if (!al || strlen(al) < 4) { set_err("2-bit input needs a matrix alphabet of at least four letters"); return -1; }
+        letters = (uint32_t)(unsigned char)al[0] | ((uint32_t)(unsigned char)al[1] << 8) | ((uint32_t)(unsigned char)al[2] << 16) | ((uint32_t)(unsigned char)al[3] << 24);
+    }
     // device staging is kept per host thread between calls (hipMalloc / hipFree of hundreds of MB cost milliseconds)
-    struct { uint8_t *p; } dq, dr; struct { int64_t *p; } dqo, dro; struct { pmx_record_t *p; } drec; struct { pmx_stats_t *p; } dst = {nullptr};
+    struct { uint8_t *p; } dq, dr, dq2 = {nullptr}, dr2 = {nullptr}; struct { int64_t *p; } dqo, dro; struct { pmx_record_t *p; } drec; struct { pmx_stats_t *p; } dst = {nullptr};
     const bool stats = cfg->want & PMX_WANT_STATS;
     if (stats && !stats_out) { set_err("stats requested without a stats buffer"); return -1; }
-    if (scratch_reserve(qbytes, (void **)&dq.p, SCR_HQ) || scratch_reserve(rbytes, (void **)&dr.p, SCR_HR) ||
+    if (scratch_reserve(qbytes + 16, (void **)&dq.p, SCR_HQ) || scratch_reserve(rbytes + 16, (void **)&dr.p, SCR_HR) ||
         scratch_reserve(sizeof(int64_t) * (n + 1), (void **)&dqo.p, SCR_HQO) || scratch_reserve(sizeof(int64_t) * (n + 1), (void **)&dro.p, SCR_HRO) ||
         scratch_reserve(sizeof(pmx_record_t) * n, (void **)&drec.p, SCR_HREC) ||
-        (stats && scratch_reserve(sizeof(pmx_stats_t) * n, (void **)&dst.p, SCR_HST))) return -1;
-    HIP_OR_RET(hipMemcpy(dqo.p, qoff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
-    HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
-    if (n >= 262144 && !(cfg->want & PMX_WANT_SORTED)) {
-        // Large uniform batches: the sequence bytes go up in slices on a copy stream while the previous slice
-        // is already being aligned on a compute stream (the offsets are absolute, so a slice is just a pointer
-        // shift); over PCIe the transfer is 3-4x the kernel time, this hides the kernel behind it.
-        static thread_local hipStream_t s_copy = nullptr, s_comp = nullptr;
-        static thread_local hipEvent_t s_ev[8];
-        static thread_local int s_dev = -1;
-        int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
-        if (s_dev != dev) {
-            if (s_copy) {                                      // the thread moved to another device: release the old device's objects
-                (void)hipStreamDestroy(s_copy); (void)hipStreamDestroy(s_comp);
-                for (auto &e : s_ev) (void)hipEventDestroy(e);
-            }
-            HIP_OR_RET(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
-            HIP_OR_RET(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
-            for (auto &e : s_ev) HIP_OR_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            s_dev = dev;
+        (stats && scratch_reserve(sizeof(pmx_stats_t) * n, (void **)&dst.p, SCR_HST)) ||
+        (packed2 && (scratch_reserve(qbytes / 4 + 16, (void **)&dq2.p, SCR_HQ2) || scratch_reserve(rbytes / 4 + 16, (void **)&dr2.p, SCR_HR2)))) return -1;
+    static thread_local hipStream_t s_copy = nullptr, s_comp = nullptr, s_back = nullptr;
+    static thread_local hipEvent_t s_ev[8], s_done[8];
+    static thread_local int s_dev = -1;
+    int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
+    if (s_dev != dev) {
+        if (s_copy) {                                      // the thread moved to another device: release the old device's objects
+            (void)hipStreamDestroy(s_copy); (void)hipStreamDestroy(s_comp); (void)hipStreamDestroy(s_back);
+            for (auto &e : s_ev) (void)hipEventDestroy(e);
+            for (auto &e : s_done) (void)hipEventDestroy(e);
         }
-        const int K = 8;
-        for (int sl = 0; sl < K; ++sl) {
-            const int64_t a = n * sl / K, e = n * (sl + 1) / K;
-            if (e <= a) continue;
+        HIP_OR_RET(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+        HIP_OR_RET(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
+        HIP_OR_RET(hipStreamCreateWithFlags(&s_back, hipStreamNonBlocking));
+        for (auto &e : s_ev) HIP_OR_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : s_done) HIP_OR_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s_dev = dev;
+    }
+    HIP_OR_RET(hipMemcpyAsync(dqo.p, qoff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s_copy));
+    HIP_OR_RET(hipMemcpyAsync(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s_copy));
+    // Large uniform batches: the sequence bytes go up in slices on a copy stream while the previous slice is already being aligned
+    // on a compute stream (the offsets are absolute, so a slice is just a pointer shift) and the slice before that travels back on a
+    // third; over PCIe the transfer is several times the kernel time, this hides the kernel and the return trip behind it.
+    const int K = (n >= 262144 && !(cfg->want & PMX_WANT_SORTED)) ? 8 : 1;
+    for (int sl = 0; sl < K; ++sl) {
+        const int64_t a = n * sl / K, e = n * (sl + 1) / K;
+        if (e <= a) continue;
+        if (packed2) {
+            const int64_t qa = qoff[a] / 4, qe = (qoff[e] + 3) / 4, ra = roff[a] / 4, re = (roff[e] + 3) / 4;
+            HIP_OR_RET(hipMemcpyAsync(dq2.p + qa, qbuf + qa, (size_t)(qe - qa), hipMemcpyHostToDevice, s_copy));
+            HIP_OR_RET(hipMemcpyAsync(dr2.p + ra, rbuf + ra, (size_t)(re - ra), hipMemcpyHostToDevice, s_copy));
+        } else {
             HIP_OR_RET(hipMemcpyAsync(dq.p + qoff[a], qbuf + qoff[a], (size_t)(qoff[e] - qoff[a]), hipMemcpyHostToDevice, s_copy));
             HIP_OR_RET(hipMemcpyAsync(dr.p + roff[a], rbuf + roff[a], (size_t)(roff[e] - roff[a]), hipMemcpyHostToDevice, s_copy));
-            HIP_OR_RET(hipEventRecord(s_ev[sl], s_copy));
-            HIP_OR_RET(hipStreamWaitEvent(s_comp, s_ev[sl], 0));
-            const int rc = pmx_align_batch_device(cfg, e - a, dq.p, dqo.p + a, dr.p, dro.p + a, mq, mr, drec.p + a,
-                                                  stats ? dst.p + a : nullptr, s_comp);
-            if (rc) { (void)hipStreamSynchronize(s_comp); return rc; }
         }
-        HIP_OR_RET(hipStreamSynchronize(s_comp));
-    } else {
-        HIP_OR_RET(hipMemcpy(dq.p, qbuf, qbytes, hipMemcpyHostToDevice));
-        HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
-        const int rc = pmx_align_batch_device(cfg, n, dq.p, dqo.p, dr.p, dro.p, mq, mr, drec.p, stats ? dst.p : nullptr, nullptr);
-        if (rc) return rc;
+        HIP_OR_RET(hipEventRecord(s_ev[sl], s_copy));
+        HIP_OR_RET(hipStreamWaitEvent(s_comp, s_ev[sl], 0));
+        if (packed2) {
+            int rc2 = pmx_launch_unpack2(dq2.p, dq.p, qoff[a], qoff[e], letters, s_comp);
+            if (!rc2) rc2 = pmx_launch_unpack2(dr2.p, dr.p, roff[a], roff[e], letters, s_comp);
+            if (rc2) { (void)hipStreamSynchronize(s_comp); set_err("2-bit unpack launch failed (%d)", rc2); return rc2; }
+        }
+        const int rc = pmx_align_batch_device(cfg, e - a, dq.p, dqo.p + a, dr.p, dro.p + a, mq, mr, drec.p + a,
+                                              stats ? dst.p + a : nullptr, s_comp);
+        if (rc) { (void)hipStreamSynchronize(s_comp); return rc; }
+        HIP_OR_RET(hipEventRecord(s_done[sl], s_comp));
+        HIP_OR_RET(hipStreamWaitEvent(s_back, s_done[sl], 0));
+        HIP_OR_RET(hipMemcpyAsync(out + a, drec.p + a, sizeof(pmx_record_t) * (size_t)(e - a), hipMemcpyDeviceToHost, s_back));
+        if (stats) HIP_OR_RET(hipMemcpyAsync(stats_out + a, dst.p + a, sizeof(pmx_stats_t) * (size_t)(e - a), hipMemcpyDeviceToHost, s_back));
     }
-    HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
-    if (stats) HIP_OR_RET(hipMemcpy(stats_out, dst.p, sizeof(pmx_stats_t) * n, hipMemcpyDeviceToHost));
+    HIP_OR_RET(hipStreamSynchronize(s_back));
+    HIP_OR_RET(hipStreamSynchronize(s_comp));
     return 0;
+}
+
+extern "C" int pmx_align_batch(const pmx_config_t *cfg, int64_t n,
+                               const uint8_t *qbuf, const int64_t *qoff,
+                               const uint8_t *rbuf, const int64_t *roff,
+                               pmx_record_t *out, pmx_stats_t *stats_out)
+{
+    return host_batch(cfg, n, qbuf, qoff, rbuf, roff, out, stats_out, false);
+}
+
+extern "C" int pmx_align_batch_2bit(const pmx_config_t *cfg, int64_t n,
+                                    const uint8_t *q2, const int64_t *qoff,
+                                    const uint8_t *r2, const int64_t *roff,
+                                    pmx_record_t *out, pmx_stats_t *stats_out)
+{
+    return host_batch(cfg, n, q2, qoff, r2, roff, out, stats_out, true);
 }
 
 extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_profile_t *profile, int64_t n,

@@ -75,6 +75,9 @@ int pmx_launch_sw16m(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext
 int pmx_launch_sw16m_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                            pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream);
 
+// 2-bit packed input -> ASCII letters (pmx_sort.hip)
+int pmx_launch_unpack2(const uint8_t *in, uint8_t *out, long long lo, long long hi, uint32_t letters, hipStream_t stream);
+
 // Length-sorted processing order for ragged batches (pmx_sort.hip).
 size_t pmx_sort_scratch_bytes(long long n);
 int pmx_build_length_perm(const int64_t *d_roff, long long n, void *scratch, const unsigned **perm_out, hipStream_t stream);

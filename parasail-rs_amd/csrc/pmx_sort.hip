@@ -58,3 +58,22 @@ int pmx_launch_text_offsets(const int32_t *textlen, long long n, int64_t *text_o
     return e == hipSuccess ? 0 : -(int)e;
 }
 
+
+// ---- 2-bit packed DNA input: base b of `in` (byte b / 4, bits 2 (b % 4)) -> letter code -> ASCII letter in `out[b]`, b in [lo, hi) ----
+__global__ void pmx_unpack2_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, long long lo4, long long hi, uint32_t letters)
+{
+    const long long b = (lo4 + (long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;      // four bases = one packed byte -> one dword
+    if (b >= hi) return;
+    const uint32_t p = in[b >> 2];
+    const uint32_t w = ((letters >> (8 * (p & 3))) & 0xFF) | (((letters >> (8 * ((p >> 2) & 3))) & 0xFF) << 8) |
+                       (((letters >> (8 * ((p >> 4) & 3))) & 0xFF) << 16) | (((letters >> (8 * ((p >> 6) & 3))) & 0xFF) << 24);
+    *reinterpret_cast<uint32_t *>(out + b) = w;        // (bases of the neighbouring slices inside the same dword get the same values again)
+}
+int pmx_launch_unpack2(const uint8_t *in, uint8_t *out, long long lo, long long hi, uint32_t letters, hipStream_t stream)
+{
+    if (hi <= lo) return 0;
+    const long long lo4 = lo / 4, n4 = (hi + 3) / 4 - lo4;
+    hipLaunchKernelGGL(pmx_unpack2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, in, out, lo4, hi, letters);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}

@@ -315,3 +315,27 @@ def test_two_streams_from_one_thread_share_the_scratch_safely(pkg, orc):
     want = al.align_batch_packed(None, None, rb, ro)
     got = np.concatenate([b[2].cpu().numpy() for b in batches])
     assert (got[:, 0] == want["score"]).all() and (got[:, 1] == want["end_query"]).all() and (got[:, 2] == want["end_ref"]).all()
+
+
+def test_2bit_packed_input_form(pkg, orc):
+    """pmx_align_batch_2bit: 2 bits per base, offsets in bases -- identical records to the byte form on ragged lengths (slices that do
+    not start on byte boundaries), small batches, the sliced large-batch path and with statistics."""
+    rng = np.random.default_rng(9900)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    for n, lo, hi in ((7, 1, 30), (3000, 1, 160), (300_000, 137, 151)):
+        ql = rng.integers(lo, hi + 1, size=n); rl = rng.integers(lo, hi + 1, size=n)
+        qoff = np.zeros(n + 1, dtype=np.int64); np.cumsum(ql, out=qoff[1:])
+        roff = np.zeros(n + 1, dtype=np.int64); np.cumsum(rl, out=roff[1:])
+        qbuf = wl.DNA[rng.integers(0, 4, size=int(qoff[-1]))]; rbuf = wl.DNA[rng.integers(0, 4, size=int(roff[-1]))]
+        q2, r2 = pkg.pack_2bit(qbuf), pkg.pack_2bit(rbuf)
+        for sel in ("local", "semi_global"):
+            b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).solution_width(16); getattr(b, sel)()
+            al = b.build()
+            assert (al.align_batch_2bit(q2, qoff, r2, roff) == al.align_batch_packed(qbuf, qoff, rbuf, roff)).all(), (n, sel)
+        if n == 3000:
+            al = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).solution_width(16).use_stats().build()
+            r1, s1 = al.align_batch_2bit(q2, qoff, r2, roff)
+            r0, s0 = al.align_batch_packed(qbuf, qoff, rbuf, roff)
+            assert (r1 == r0).all() and (s1 == s0).all()
+            want = orc.align_batch(orc.NW, qbuf, qoff, rbuf, roff, 5, 2, om)
+            assert (r1["score"] == want[:, 0]).all()
