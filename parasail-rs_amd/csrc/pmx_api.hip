@@ -1474,12 +1474,17 @@ static int host_batch(const pmx_config_t *cfg, int64_t n,
                                               stats ? dst.p + a : nullptr, s_comp);
         if (rc) { (void)hipStreamSynchronize(s_comp); return rc; }
         HIP_OR_RET(hipEventRecord(s_done[sl], s_comp));
-        HIP_OR_RET(hipStreamWaitEvent(s_back, s_done[sl], 0));
+    }
+    // the way back, slice by slice as they finish (a copy into pageable host memory blocks the host thread, so it is not issued
+    // inside the loop above: the later slices are already queued and keep the GPU busy meanwhile)
+    for (int sl = 0; sl < K; ++sl) {
+        const int64_t a = n * sl / K, e = n * (sl + 1) / K;
+        if (e <= a) continue;
+        HIP_OR_RET(hipEventSynchronize(s_done[sl]));
         HIP_OR_RET(hipMemcpyAsync(out + a, drec.p + a, sizeof(pmx_record_t) * (size_t)(e - a), hipMemcpyDeviceToHost, s_back));
         if (stats) HIP_OR_RET(hipMemcpyAsync(stats_out + a, dst.p + a, sizeof(pmx_stats_t) * (size_t)(e - a), hipMemcpyDeviceToHost, s_back));
     }
     HIP_OR_RET(hipStreamSynchronize(s_back));
-    HIP_OR_RET(hipStreamSynchronize(s_comp));
     return 0;
 }
 
