@@ -111,7 +111,9 @@ def pmc_summary(config, kernel):
             return None
         out = {"source": os.path.relpath(files[-1], ROOT), "profiled_kernel": d.get("kernel")}
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-            out["traffic"] = int((2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+            per_step = float(d.get("launches_per_step", 1.0))       # chunked pipelines launch the sweep several times per step
+            out["traffic"] = int((2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024 * per_step)
+            out["launches_per_step"] = per_step
         if "SQ_LDS_BANK_CONFLICT" in d and "SQ_LDS_IDX_ACTIVE" in d:
             out["lds_bank_conflict"] = {"conflict_cycles": int(d["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"]),
                                         "lds_active_cycles": int(d["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"]),

@@ -10,8 +10,8 @@ for spec in "2 pmx_sw16_kernel<8,_19,_6>" "3 pmx_nwsg16q_kernel" "4 pmx_nwsg16v_
     bash /root/repo/profiles/run_profile.sh $TAG $1 "$2" > /root/repo/gpurun_out/collect_${TAG}_cfg$1.log 2>&1
     OUT=/root/repo/gpurun_out/prof_${TAG}_cfg$1
     cp $OUT/cfg$1_pmc_summary.json $OUT/cfg$1_kernel_stats.csv /root/repo/profiles/$TAG/ 2>/dev/null
-    if [ "$1" = "4" ]; then python3 /root/repo/profiles/summarize_pmc.py $OUT pmx_walkp_kernel /root/repo/profiles/$TAG/cfg4_walk_pmc_summary.json; fi
-    if [ "$1" = "3" ]; then python3 /root/repo/profiles/summarize_pmc.py $OUT pmx_walkp_kernel /root/repo/profiles/$TAG/cfg3_walk_pmc_summary.json; fi
+    if [ "$1" = "4" ]; then python3 /root/repo/profiles/summarize_pmc.py $OUT pmx_walkp_kernel /root/repo/profiles/$TAG/cfg4_walk_pmc_summary.json 6; fi
+    if [ "$1" = "3" ]; then python3 /root/repo/profiles/summarize_pmc.py $OUT pmx_walkp_kernel /root/repo/profiles/$TAG/cfg3_walk_pmc_summary.json 6; fi
     echo "cfg$1 done"; tail -3 /root/repo/gpurun_out/collect_${TAG}_cfg$1.log
 done
 cp -r /root/repo/profiles/$TAG /root/repo/gpurun_out/profiles_$TAG

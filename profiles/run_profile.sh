@@ -22,6 +22,6 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fet
 echo "pmc_fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
 echo "pmc_write rc=$?"
-python3 /root/repo/profiles/summarize_pmc.py $OUT "$NEEDLE" $OUT/cfg${CFG}_pmc_summary.json
+python3 /root/repo/profiles/summarize_pmc.py $OUT "$NEEDLE" $OUT/cfg${CFG}_pmc_summary.json 6
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/cfg${CFG}_kernel_stats.csv 2>/dev/null
 ls $OUT
