@@ -5,8 +5,8 @@
 # (profiles/<tag>/cfgN_pmc_summary.json, cfgN_kernel_stats.csv).
 TAG=${1:-r02}
 mkdir -p /root/repo/profiles/$TAG
-for spec in "2 pmx_sw16_kernel<8,_19,_6>" "3 pmx_nwsg16q_kernel" "4 pmx_nwsg16v_kernel" "5 pmx_sw16_kernel<64,_16,_6>"; do
-    set -- $spec; set -- $1 "${2//_/ }"
+for spec in "2|pmx_sw16_kernel<8, 19, 6>" "3|pmx_nwsg16q_kernel" "4|pmx_nwsg16v_kernel" "5|pmx_sw16_kernel<64, 16, 6>"; do
+    set -- "${spec%%|*}" "${spec#*|}"
     bash /root/repo/profiles/run_profile.sh $TAG $1 "$2" > /root/repo/gpurun_out/collect_${TAG}_cfg$1.log 2>&1
     OUT=/root/repo/gpurun_out/prof_${TAG}_cfg$1
     cp $OUT/cfg$1_pmc_summary.json $OUT/cfg$1_kernel_stats.csv /root/repo/profiles/$TAG/ 2>/dev/null
