@@ -547,6 +547,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     // or a diagonal sits in one cache line (consecutive stores of a lane fill its 128-byte lines in L2)
     const size_t t_ss = 4;
     uint32_t *tw = TR ? tbuf + ((size_t)blockIdx.x * Tmax) * 256 + (size_t)lane * Tmax * 4 : nullptr;
+    uint4 wprev = {0u, 0u, 0u, 0u};
     const v2s two2 = {2, 2}, sh15 = {15, 15};
     auto push = [&](v2s &pl, int a, int b) {         // pl = 2 * pl + (a < b), per half
         const v2s bit = PK(I32(__builtin_bit_cast(v2us, PK(a) - PK(b)) >> __builtin_bit_cast(v2us, sh15)));
@@ -609,7 +610,11 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             w.y = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x00010405);
             w.z = __builtin_amdgcn_perm(I32(plane[0]), I32(plane[1]), 0x02030607);   // B
             w.w = __builtin_amdgcn_perm(I32(plane[2]), I32(plane[3]), 0x02030607);
-            *reinterpret_cast<uint4 *>(tw + (size_t)t * t_ss) = w;
+            // two steps leave together: 32 contiguous bytes per lane = one whole sector (single 16-byte stores of thousands of
+            // resident lanes reach HBM as partly written sectors: PMC WRITE_SIZE was 1.7x the bytes stored; four steps per group
+            // cost more registers than they save: 26.6 ms against 25.6 ms per cfg-4 step)
+            if (t & 1) { uint4 *dst = reinterpret_cast<uint4 *>(tw + (size_t)(t - 1) * t_ss); dst[0] = wprev; dst[1] = w; }
+            else wprev = w;
         }
         diag0 = Hin;
         Hout = Hnew[R - 1];
