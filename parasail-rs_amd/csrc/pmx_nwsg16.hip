@@ -33,6 +33,9 @@ typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 #define PK(x)  __builtin_bit_cast(v2s, (int)(x))
 #define I32(x) __builtin_bit_cast(int, (x))
 
+#ifndef PMX_QSTAGE
+#define PMX_QSTAGE 8                   // steps of trace records the shared-profile sweep gathers in LDS per flush (4 or 8)
+#endif
 #define NB 16384                       // bias
 #define NB2 ((NB << 16) | NB)
 #define NEGS ((short)-32768)           // "-inf" score: sets the sign bit of the biased sum
@@ -774,7 +777,8 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
     long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));   // per pair: r offset, rlen, pair index
     // TR: eight steps of every lane's trace records are gathered in LDS and leave as one contiguous piece of the lane's stream
     // (96 or 128 bytes: whole 32-byte sectors; single 12/16-byte stores of thousands of resident lanes overflow the L2's write combining)
-    constexpr int TSTR = 8 * TD + 1;              // dwords per lane (odd: the lanes' stores of a step fall into different banks)
+    constexpr int TSTG = PMX_QSTAGE;               // steps gathered per flush
+    constexpr int TSTR = TSTG * TD + 1;              // dwords per lane (odd: the lanes' stores of a step fall into different banks)
     uint32_t *tstage = reinterpret_cast<uint32_t *>(ptab + 3 * NP) + (size_t)(wave * 64 + lane) * TSTR;
 
     const long long pair0 = (long long)blockIdx.x * NP;
@@ -886,7 +890,7 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
             // record: [A bytes 0 .. R/2-1][B bytes 0 .. R/2-1][pad]; u = [A_y A_y+1 B_y B_y+1] of two row pairs
             const int u01 = __builtin_amdgcn_perm(ty[0], ty[1], 0x03070105), u23 = __builtin_amdgcn_perm(ty[2], ty[3], 0x03070105);
             const int a0 = __builtin_amdgcn_perm(u01, u23, 0x01000504), b0 = __builtin_amdgcn_perm(u01, u23, 0x03020706);
-            uint32_t *dst = tstage + (t & 7) * TD;
+            uint32_t *dst = tstage + (t & (TSTG - 1)) * TD;
             if (R == 16) {
                 const int u45 = __builtin_amdgcn_perm(ty[4], ty[R == 16 ? 5 : 0], 0x03070105), u67 = __builtin_amdgcn_perm(ty[R == 16 ? 6 : 0], ty[R == 16 ? 7 : 0], 0x03070105);
                 dst[0] = (uint32_t)a0; dst[1] = (uint32_t)__builtin_amdgcn_perm(u45, u67, 0x01000504);
@@ -954,10 +958,10 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
         __builtin_amdgcn_sched_barrier(0);
         step(1, t + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (TR && ((t & 6) == 6 || t + 2 >= T)) {          // eight steps gathered (or the sweep ends): one piece of the lane's stream
-            uint4 *gdst = reinterpret_cast<uint4 *>(tw + (size_t)(t & ~7) * TD);
+        if (TR && ((t & (TSTG - 2)) == (TSTG - 2) || t + 2 >= T)) {          // TSTG steps gathered (or the sweep ends): one piece of the lane's stream
+            uint4 *gdst = reinterpret_cast<uint4 *>(tw + (size_t)(t & ~(TSTG - 1)) * TD);
 #pragma unroll
-            for (int x = 0; x < 2 * TD; ++x) {
+            for (int x = 0; x < TSTG * TD / 4; ++x) {
                 uint4 v; v.x = tstage[4 * x]; v.y = tstage[4 * x + 1]; v.z = tstage[4 * x + 2]; v.w = tstage[4 * x + 3];
                 gdst[x] = v;
             }
@@ -1285,7 +1289,7 @@ static int launch_nwsgq(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
 {
     constexpr int RS = (R + 3) / 4 * 4, WAVES = 4, NP = 2 * (64 / G) * WAVES;
     const size_t lds = (size_t)(m.msize + 1) * G * RS + 8 + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 24 +
-                       (TR ? (size_t)WAVES * 64 * (8 * ((R + 3) / 4) + 1) * 4 : 0);
+                       (TR ? (size_t)WAVES * 64 * (PMX_QSTAGE * ((R + 3) / 4) + 1) * 4 : 0);
     if (lds > 160 * 1024) return 1;
     { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16q_kernel<G, R, WAVES, TR>)); if (rc) return rc; }
     const bool sg = mode == PMX_MODE_SG;
@@ -1313,7 +1317,7 @@ int pmx_nwsgq_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
         const int G = kQShapeG[v], R = kQShapeR[v];
         if (b.q_shared > G * R - 1) continue;
         const size_t lds = (size_t)(m.msize + 1) * G * ((R + 3) / 4 * 4) + 8 + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)(2 * (64 / G) * 4) * 24 +
-                           (size_t)4 * 64 * (8 * ((R + 3) / 4) + 1) * 4;
+                           (size_t)4 * 64 * (PMX_QSTAGE * ((R + 3) / 4) + 1) * 4;
         if (lds > 160 * 1024) continue;
         const long long NP = 2 * (64 / G) * 4;
         *variant = 30 + v; *G_out = G; *R_out = R;
