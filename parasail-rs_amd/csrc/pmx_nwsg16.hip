@@ -958,12 +958,18 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
         __builtin_amdgcn_sched_barrier(0);
         step(1, t + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (TR && ((t & (TSTG - 2)) == (TSTG - 2) || t + 2 >= T)) {          // TSTG steps gathered (or the sweep ends): one piece of the lane's stream
-            uint4 *gdst = reinterpret_cast<uint4 *>(tw + (size_t)(t & ~(TSTG - 1)) * TD);
+        if (TR && ((t & (TSTG - 2)) == (TSTG - 2) || t + 2 >= T)) {          // TSTG steps gathered (or the sweep ends)
+            // The wave's 64 pieces of lane stream (TSTG * TD dwords each, contiguous in HBM) leave together: item w = 16-byte piece
+            // w % PPS of lane stream w / PPS, so neighbouring lanes write neighbouring bytes and every store covers whole stretches
+            constexpr int PPS = TSTG * TD / 4;                            // 16-byte pieces per stream and flush
+            const uint32_t *wstage = tstage - (size_t)lane * TSTR;        // the wave's staging area
+            uint32_t *wtw = tw - (size_t)lane * Tmax * TD;                // the wave's lane stream 0
 #pragma unroll
-            for (int x = 0; x < TSTG * TD / 4; ++x) {
-                uint4 v; v.x = tstage[4 * x]; v.y = tstage[4 * x + 1]; v.z = tstage[4 * x + 2]; v.w = tstage[4 * x + 3];
-                gdst[x] = v;
+            for (int x = 0; x < PPS; ++x) {
+                const int w = x * 64 + lane, stream = w / PPS, piece = w - stream * PPS;
+                const uint32_t *src = wstage + stream * TSTR + piece * 4;
+                uint4 v; v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+                *reinterpret_cast<uint4 *>(wtw + ((size_t)stream * Tmax + (size_t)(t & ~(TSTG - 1))) * TD + piece * 4) = v;
             }
         }
     }
