@@ -188,32 +188,31 @@ class Cfg2(Workload):
     def pcie_inclusive(self):
         c = wl.CFG2
         al = self.pkg.Aligner.new().local().matrix(self.matrix).gap_open(c["open"]).gap_extend(c["ext"]).solution_width(16).build()
-        al.align_batch_packed(*self.h)
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter(); al.align_batch_packed(*self.h); ts.append(time.perf_counter() - t0)
-        res = {"value": round(self.cells / min(ts) / 1e9, 1), "unit": "GCUPS", "ms": round(min(ts) * 1e3, 3),
+        out = np.zeros(self.n, dtype=self.pkg.RECORD_DTYPE)        # the caller's result buffer, reused from call to call
+
+        def best(f):
+            f(); ts = []
+            for _ in range(5):
+                t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
+            return min(ts)
+        t = best(lambda: al.align_batch_packed(*self.h, out=out))
+        res = {"value": round(self.cells / t / 1e9, 1), "unit": "GCUPS", "ms": round(t * 1e3, 3),
                "entry": "pmx_align_batch (pageable host buffers in, host records out)"}
+        ref = out.copy()
         try:                                   # the same with the caller's buffers page-locked once (pmx_host_register)
-            self.pkg.host_register(*self.h)
-            al.align_batch_packed(*self.h)
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter(); al.align_batch_packed(*self.h); ts.append(time.perf_counter() - t0)
-            res["pinned"] = {"value": round(self.cells / min(ts) / 1e9, 1), "unit": "GCUPS", "ms": round(min(ts) * 1e3, 3),
+            self.pkg.host_register(*self.h, out)
+            t = best(lambda: al.align_batch_packed(*self.h, out=out))
+            res["pinned"] = {"value": round(self.cells / t / 1e9, 1), "unit": "GCUPS", "ms": round(t * 1e3, 3),
                              "entry": "pmx_align_batch, host buffers page-locked by the caller (pmx_host_register)"}
         finally:
-            self.pkg.host_unregister(*self.h)
+            self.pkg.host_unregister(*self.h, out)
         # 2-bit packed input form (a quarter of the sequence bytes over PCIe, spelled out on the device)
         q2, r2 = self.pkg.pack_2bit(self.h[0]), self.pkg.pack_2bit(self.h[2])
-        ref = al.align_batch_packed(*self.h)
-        got = al.align_batch_2bit(q2, self.h[1], r2, self.h[3])
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter(); al.align_batch_2bit(q2, self.h[1], r2, self.h[3]); ts.append(time.perf_counter() - t0)
-        res["packed_2bit"] = {"value": round(self.cells / min(ts) / 1e9, 1), "unit": "GCUPS", "ms": round(min(ts) * 1e3, 3),
+        out[:] = 0
+        t = best(lambda: al.align_batch_2bit(q2, self.h[1], r2, self.h[3], out=out))
+        res["packed_2bit"] = {"value": round(self.cells / t / 1e9, 1), "unit": "GCUPS", "ms": round(t * 1e3, 3),
                               "entry": "pmx_align_batch_2bit (2 bits per base in pageable host buffers, host records out)",
-                              "identical_records": bool((got == ref).all())}
+                              "identical_records": bool((out == ref).all())}
         return res
 
     def cpu_baseline(self, last_out):

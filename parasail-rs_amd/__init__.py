@@ -747,10 +747,11 @@ class Aligner:
         rbuf, roff = pack(references)
         return self.align_batch_packed(qbuf, qoff, rbuf, roff)
 
-    def align_batch_packed(self, qbuf, qoff, rbuf, roff):
+    def align_batch_packed(self, qbuf, qoff, rbuf, roff, out=None):
+        """`out`: a RECORD_DTYPE array of n records to fill (a caller that aligns batch after batch reuses one, already paged in)."""
         n = len(roff) - 1
         cfg = self._config()
-        out = np.zeros(n, dtype=RECORD_DTYPE)
+        out = _record_buffer(out, n)
         stats = np.zeros(n, dtype=STATS_DTYPE) if cfg.want & WANT_STATS else None
         if self._profile.is_null():
             if len(qoff) - 1 != n:
@@ -765,11 +766,11 @@ class Aligner:
             raise BatchError(lib.pmx_last_error().decode())
         return (out, stats) if stats is not None else out
 
-    def align_batch_2bit(self, q2, qoff, r2, roff):
-        """2-bit packed input (see pack_2bit): offsets count bases."""
+    def align_batch_2bit(self, q2, qoff, r2, roff, out=None):
+        """2-bit packed input (see pack_2bit): offsets count bases.  `out` as in align_batch_packed."""
         n = len(roff) - 1
         cfg = self._config()
-        out = np.zeros(n, dtype=RECORD_DTYPE)
+        out = _record_buffer(out, n)
         stats = np.zeros(n, dtype=STATS_DTYPE) if cfg.want & WANT_STATS else None
         rc = lib.pmx_align_batch_2bit(C.byref(cfg), n, q2.ctypes.data, qoff.ctypes.data, r2.ctypes.data, roff.ctypes.data,
                                       out.ctypes.data, stats.ctypes.data if stats is not None else None)
@@ -910,6 +911,14 @@ def pack_2bit(buf, alphabet=b"ACGT"):
         codes = np.concatenate([codes, np.zeros(pad, dtype=np.uint8)])
     c = codes.reshape(-1, 4)
     return (c[:, 0] | (c[:, 1] << 2) | (c[:, 2] << 4) | (c[:, 3] << 6)).astype(np.uint8)
+
+
+def _record_buffer(out, n):
+    if out is None:
+        return np.zeros(n, dtype=RECORD_DTYPE)
+    if out.dtype != RECORD_DTYPE or out.shape != (n,) or not out.flags.c_contiguous:
+        raise BatchError("out must be a contiguous RECORD_DTYPE array of %d records" % n)
+    return out
 
 
 def host_register(*arrays):

@@ -6,6 +6,8 @@
 // All DP arithmetic is done by the HIP kernels (pmx_sw16.hip, pmx_general.hip); this file
 // owns handles, dispatch-name parsing, device staging and result marshalling only.
 #include "pmx_common.h"
+#include <chrono>
+#include <future>
 #include "pmx_matrices.h"
 
 #include <cctype>
@@ -1379,15 +1381,37 @@ extern "C" int pmx_align_batch_device(const pmx_config_t *cfg, int64_t n,
 
 static void host_maxlens(int64_t n, const int64_t *off, int32_t *mx, bool *bad, int32_t *mn = nullptr)
 {
-    int64_t m = 0, lo = INT32_MAX;
+    int64_t m = 0, lo = INT32_MAX;                  // (no stores inside the loop: one compare-select pair per element)
     for (int64_t k = 0; k < n; ++k) {
         const int64_t l = off[k + 1] - off[k];
-        if (l <= 0 || l > INT32_MAX) *bad = true;
         m = l > m ? l : m;
         lo = l < lo ? l : lo;
     }
-    *mx = (int32_t)m;
-    if (mn) *mn = (int32_t)lo;
+    if (lo <= 0 || m > INT32_MAX) *bad = true;
+    *mx = (int32_t)(m > INT32_MAX ? INT32_MAX : m);
+    if (mn) *mn = (int32_t)(lo < 0 ? 0 : lo);
+}
+// The same over both offset arrays of a large batch, split over a few host threads: the scan of 2 x 1M offsets is 1.2 ms on one
+// core, as long as a third of the device work it precedes.
+struct LenScan { int32_t mq = 0, mr = 0, mnr = INT32_MAX; bool bad = false; };
+static LenScan scan_lengths(int64_t n, const int64_t *qoff, const int64_t *roff)
+{
+    const int T = n >= 262144 ? 4 : 1;
+    LenScan part[4];
+    auto work = [&](int t) {
+        const int64_t a = n * t / T, e = n * (t + 1) / T;
+        host_maxlens(e - a, qoff + a, &part[t].mq, &part[t].bad);
+        host_maxlens(e - a, roff + a, &part[t].mr, &part[t].bad, &part[t].mnr);
+    };
+    std::thread th[3];
+    for (int t = 1; t < T; ++t) th[t - 1] = std::thread(work, t);
+    work(0);
+    for (int t = 1; t < T; ++t) th[t - 1].join();
+    LenScan r = part[0];
+    for (int t = 1; t < T; ++t) {
+        r.mq = std::max(r.mq, part[t].mq); r.mr = std::max(r.mr, part[t].mr); r.mnr = std::min(r.mnr, part[t].mnr); r.bad |= part[t].bad;
+    }
+    return r;
 }
 // ragged reference lengths: worth a length-sorted processing order
 static pmx_config_t with_sort_hint(const pmx_config_t *cfg, int32_t min_rlen, int32_t max_rlen, int64_t n)
@@ -1407,13 +1431,15 @@ static int host_batch(const pmx_config_t *cfg, int64_t n,
     if (check_cfg(cfg)) return -1;
     if (n <= 0) return 0;
     if (!qbuf || !qoff || !rbuf || !roff || !out) { set_err("null buffer"); return -1; }
-    int32_t mq = 0, mr = 0, mnr = 0; bool bad = false;
-    host_maxlens(n, qoff, &mq, &bad); host_maxlens(n, roff, &mr, &bad, &mnr);
-    if (bad) { set_err("every sequence must have length >= 1"); return -1; }
-    const pmx_config_t cfg_s = with_sort_hint(cfg, mnr, mr, n);
-    cfg = &cfg_s;
-    const size_t qbytes = (size_t)(qoff[n] - qoff[0]), rbytes = (size_t)(roff[n] - roff[0]);
+    // the length scan runs beside the first transfers (it needs the host only; the offsets go up meanwhile)
+    LenScan ls;
+    std::future<void> scan;
+    if (n >= 262144) scan = std::async(std::launch::async, [&]() { ls = scan_lengths(n, qoff, roff); });
+    else ls = scan_lengths(n, qoff, roff);
+    struct ScanJoin { std::future<void> &f; ~ScanJoin() { if (f.valid()) f.wait(); } } scan_join{scan};     // (early returns)
     if (qoff[0] != 0 || roff[0] != 0) { set_err("offset arrays must start at 0"); return -1; }
+    if (qoff[n] <= 0 || roff[n] <= 0 || qoff[n] > ((int64_t)1 << 40) || roff[n] > ((int64_t)1 << 40)) { set_err("bad offset arrays"); return -1; }
+    const size_t qbytes = (size_t)qoff[n], rbytes = (size_t)roff[n];
     uint32_t letters = 0;
     if (packed2) {
         const char *al = cfg->matrix->alphabet;
@@ -1448,10 +1474,15 @@ static int host_batch(const pmx_config_t *cfg, int64_t n,
     }
     HIP_OR_RET(hipMemcpyAsync(dqo.p, qoff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s_copy));
     HIP_OR_RET(hipMemcpyAsync(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s_copy));
+    if (scan.valid()) scan.get();
+    if (ls.bad) { (void)hipStreamSynchronize(s_copy); set_err("every sequence must have length >= 1"); return -1; }
+    const int32_t mq = ls.mq, mr = ls.mr;
+    const pmx_config_t cfg_s = with_sort_hint(cfg, ls.mnr, mr, n);
+    cfg = &cfg_s;
     // Large uniform batches: the sequence bytes go up in slices on a copy stream while the previous slice is already being aligned
     // on a compute stream (the offsets are absolute, so a slice is just a pointer shift) and the slice before that travels back on a
     // third; over PCIe the transfer is several times the kernel time, this hides the kernel and the return trip behind it.
-    const int K = (n >= 262144 && !(cfg->want & PMX_WANT_SORTED)) ? 8 : 1;
+    const int K = (n >= 262144 && !(cfg->want & PMX_WANT_SORTED)) ? (packed2 ? 4 : 8) : 1;     // (2-bit input: the kernel, not the link, is the longer leg)
     for (int sl = 0; sl < K; ++sl) {
         const int64_t a = n * sl / K, e = n * (sl + 1) / K;
         if (e <= a) continue;
@@ -1474,14 +1505,14 @@ static int host_batch(const pmx_config_t *cfg, int64_t n,
                                               stats ? dst.p + a : nullptr, s_comp);
         if (rc) { (void)hipStreamSynchronize(s_comp); return rc; }
         HIP_OR_RET(hipEventRecord(s_done[sl], s_comp));
-    }
+        }
     // the way back, slice by slice as they finish (a copy into pageable host memory blocks the host thread, so it is not issued
     // inside the loop above: the later slices are already queued and keep the GPU busy meanwhile)
     for (int sl = 0; sl < K; ++sl) {
         const int64_t a = n * sl / K, e = n * (sl + 1) / K;
         if (e <= a) continue;
         HIP_OR_RET(hipEventSynchronize(s_done[sl]));
-        HIP_OR_RET(hipMemcpyAsync(out + a, drec.p + a, sizeof(pmx_record_t) * (size_t)(e - a), hipMemcpyDeviceToHost, s_back));
+            HIP_OR_RET(hipMemcpyAsync(out + a, drec.p + a, sizeof(pmx_record_t) * (size_t)(e - a), hipMemcpyDeviceToHost, s_back));
         if (stats) HIP_OR_RET(hipMemcpyAsync(stats_out + a, dst.p + a, sizeof(pmx_stats_t) * (size_t)(e - a), hipMemcpyDeviceToHost, s_back));
     }
     HIP_OR_RET(hipStreamSynchronize(s_back));

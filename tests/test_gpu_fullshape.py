@@ -339,3 +339,29 @@ def test_2bit_packed_input_form(pkg, orc):
             assert (r1 == r0).all() and (s1 == s0).all()
             want = orc.align_batch(orc.NW, qbuf, qoff, rbuf, roff, 5, 2, om)
             assert (r1["score"] == want[:, 0]).all()
+
+
+def test_host_entry_large_batch_guards(pkg, orc):
+    """The large-batch host path (length scan on helper threads beside the offset transfers, sliced pipeline): an empty sequence
+    anywhere in the batch is refused before any kernel runs, a caller-supplied result buffer is filled in place, and the records
+    of a 300k-pair batch equal the oracle's on a sample."""
+    rng = np.random.default_rng(9911)
+    n, L = 300_000, 96
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qbuf = wl.DNA[rng.integers(0, 4, size=n * L)]; rbuf = wl.DNA[rng.integers(0, 4, size=n * L)]
+    off = wl.uniform_offsets(n, L)
+    al = pkg.Aligner.new().local().matrix(pm).gap_open(5).gap_extend(2).solution_width(16).build()
+    out = np.zeros(n, dtype=pkg.RECORD_DTYPE)
+    got = al.align_batch_packed(qbuf, off, rbuf, off, out=out)
+    assert got is out
+    idx = rng.choice(n, size=300, replace=False)
+    for k in idx:
+        w = orc.align(orc.SW, qbuf[off[k]:off[k + 1]].tobytes(), rbuf[off[k]:off[k + 1]].tobytes(), 5, 2, om)
+        assert (out["score"][k], out["end_query"][k], out["end_ref"][k]) == (w.score, w.end_query, w.end_ref), k
+    for where in (0, n // 2 + 17, n - 1):                      # one empty reference, in the first, a middle and the last scan block
+        bad = off.copy(); bad[where + 1:] -= L; bad[where + 1] = bad[where]
+        bad = np.ascontiguousarray(bad)
+        with pytest.raises(pkg.BatchError):
+            al.align_batch_packed(qbuf, off, rbuf[: int(bad[-1]) if bad[-1] > 0 else 1], bad)
+    with pytest.raises(pkg.BatchError):
+        al.align_batch_packed(qbuf, off, rbuf, off, out=np.zeros(n - 1, dtype=pkg.RECORD_DTYPE))
