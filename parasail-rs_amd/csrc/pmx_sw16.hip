@@ -441,13 +441,17 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
             const v2s sh = {15, 15};
             m = I32(dd >> sh);                              // v_pk_ashrrev_i16
         }
-        // v_bfi_b32 d = (m & a) | (~m & b)
-        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bestcol) : "v"(m), "s"((t & 0xFFFF) * 0x00010001), "v"(bestcol));   // the step index is uniform: SGPR operand
+        // The strip is saved only in steps where some lane of the wave improves (a wave-uniform branch around R + 1 v_bfi_b32):
+        // improvements get rare as a sweep goes on -- a lane's best is a running maximum -- so long sweeps skip most saves.
+        if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+            // v_bfi_b32 d = (m & a) | (~m & b)
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bestcol) : "v"(m), "s"((t & 0xFFFF) * 0x00010001), "v"(bestcol));   // the step index is uniform: SGPR operand
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            int hs;
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hs) : "v"(m), "v"(I32((V2 && !SK) ? Hcur[k] : Hnew[k])), "v"(I32(Hsave[k])));
-            Hsave[k] = PK(hs);
+            for (int k = 0; k < R; ++k) {
+                int hs;
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hs) : "v"(m), "v"(I32((V2 && !SK) ? Hcur[k] : Hnew[k])), "v"(I32(Hsave[k])));
+                Hsave[k] = PK(hs);
+            }
         }
         best = SK ? PK(I32(nb) + I32(vExt)) : nb;                           // SK: carried into the next column's skew
         if (SK) Zv += I32(vExt);
