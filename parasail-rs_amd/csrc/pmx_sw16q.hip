@@ -149,12 +149,14 @@ void pmx_sw16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
         const int nb = q_max3(best, colmax, colmax);
         const q_v2s sh = {15, 15};
         const int m = Q_I32((Q_PK(best) - Q_PK(colmax)) >> sh);     // 0xFFFF where the column maximum strictly exceeds the best so far
-        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bestcol) : "v"(m), "s"((t & 0xFFFF) * 0x00010001), "v"(bestcol));
+        if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {            // (wave-uniform: most steps of a long sweep improve no lane's best)
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bestcol) : "v"(m), "s"((t & 0xFFFF) * 0x00010001), "v"(bestcol));
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            int hs;
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hs) : "v"(m), "v"(X[k]), "v"(Hsave[k]));
-            Hsave[k] = hs;
+            for (int k = 0; k < R; ++k) {
+                int hs;
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hs) : "v"(m), "v"(X[k]), "v"(Hsave[k]));
+                Hsave[k] = hs;
+            }
         }
         best = nb + vExt;
         Zv += vExt;
