@@ -87,6 +87,9 @@ __device__ __forceinline__ v2s pk_max3f(v2s a, v2s b, v2s c)   // integer max3 o
                                                 __builtin_bit_cast(v2h, c));
     return __builtin_bit_cast(v2s, r);
 }
+#ifndef PMX_SHARE_PERIOD
+#define PMX_SHARE_PERIOD 16     // steps between two exchanges of the group's score bound (a power of two; see share_bound)
+#endif
 #define FLOOR2 0x80008000   // both halves = -32768 = "zero" of the offset domain
 
 template <int G, int R, int VAR>
@@ -480,7 +483,23 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         load_scores(rsA[0], rsB[0], w0a, w0b);
         nsA = rsA[1]; nsB = rsB[1];
     }
+    // Every 16 steps the lanes of a group agree on a lower bound of their pair's final score -- the largest best any of them holds
+    // (compared with the lane-dependent part of the skew taken off) -- and each raises its own `best` to one BELOW it: a lane
+    // whose column maxima stay under the bound can no longer hold the pair's end cell, so its improvements need no strip save,
+    // while a lane that reaches the bound itself (a tie, decided by column and row in the epilogue) still saves.  Lanes that
+    // end with a raised, never-reached `best` carry a value below the pair's score into the final reduction and lose there.
+    auto share_bound = [&]() {
+        int v = I32(best) - skew0;
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            const int o = __shfl_xor(v, (IL ? 2 : 1) * off, 64);
+            v = I32(pk_max3f(PK(v), PK(o), PK(o)));
+        }
+        v = v - 0x00010001 + skew0;
+        best = pk_max3f(best, PK(v), PK(v));
+    };
     for (int t = 0; t + 1 < T; t += 2) {
+        if (SK && G > 1 && (t & (PMX_SHARE_PERIOD - 1)) == 0 && t) share_bound();
         load_scores(nsA, nsB, w1a, w1b);
         if (FETCH) { nsA = symA_of(m2a); nsB = symB_of(m2b); fetch(t + 4, m2a, m2b); }
         else { nsA = rsA[t + 2]; nsB = rsB[t + 2]; }
