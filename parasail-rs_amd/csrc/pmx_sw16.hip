@@ -315,6 +315,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     for (int k = 0; k < R; ++k) { HA[k] = vInitH; HB[k] = vInitH; E[k] = V2 ? vInitH : (M3 ? PK(0) : vZero); Hsave[k] = vZero; }
     v2s best = PK(ZERO2 + skew0 - (SK ? I32(vC) : 0));     // SK: X form
     int bestcol = g * 0x00010001;             // STEP at which the best was first exceeded (column = step - g; initially column 0)
+    int vprev = 0, fake = 0;                  // see share_bound
     int Zv = ZERO2 + skew0 + I32(vExt);       // SK: "F^ = 0" of the current column; += ext per step
     const int HNEUTRAL = V2 ? ZERO2 - I32(vOpen) : ZERO2;
     // last-row H (V2: H - open) and outgoing F of the previous step; SK: what lane g+1 reads at step 0
@@ -449,6 +450,7 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
             // v_bfi_b32 d = (m & a) | (~m & b)
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bestcol) : "v"(m), "s"((t & 0xFFFF) * 0x00010001), "v"(bestcol));   // the step index is uniform: SGPR operand
+            fake &= ~m;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 int hs;
@@ -488,6 +490,12 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
     // whose column maxima stay under the bound can no longer hold the pair's end cell, so its improvements need no strip save,
     // while a lane that reaches the bound itself (a tie, decided by column and row in the epilogue) still saves.  Lanes that
     // end with a raised, never-reached `best` carry a value below the pair's score into the final reduction and lose there.
+    // Ties: a lane that only EQUALS the bound matters if its cell precedes the holder's in column-major order, which needs an
+    // earlier column -- impossible once G steps have passed since the holder got there (lane g works on column step - g).  So
+    // the bound of the PREVIOUS exchange (SHP >= G steps old) is applied in full, the fresh one less one.  A `best` raised this
+    // way is not a score the lane has seen: `fake` marks those halves until the lane's next real improvement, and the epilogue
+    // drops them (they could otherwise tie with the true end cell's score).
+    constexpr int SHP = PMX_SHARE_PERIOD > G ? PMX_SHARE_PERIOD : G;
     auto share_bound = [&]() {
         int v = I32(best) - skew0;
 #pragma unroll
@@ -495,11 +503,16 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
             const int o = __shfl_xor(v, (IL ? 2 : 1) * off, 64);
             v = I32(pk_max3f(PK(v), PK(o), PK(o)));
         }
-        v = v - 0x00010001 + skew0;
-        best = pk_max3f(best, PK(v), PK(v));
+        const int fresh = v - 0x00010001 + skew0;
+        const int old = vprev ? vprev + ((SHP * ext) & 0xFFFF) * 0x00010001 + skew0 : 0;        // (0: below every live value)
+        const v2s nbest = pk_max3f(best, PK(fresh), PK(old));
+        const v2s sh = {15, 15};
+        fake |= I32((best - nbest) >> sh);                  // halves that were raised
+        best = nbest;
+        vprev = v;
     };
     for (int t = 0; t + 1 < T; t += 2) {
-        if (SK && G > 1 && (t & (PMX_SHARE_PERIOD - 1)) == 0 && t) share_bound();
+        if (SK && G > 1 && (t & (SHP - 1)) == 0 && t) share_bound();
         load_scores(nsA, nsB, w1a, w1b);
         if (FETCH) { nsA = symA_of(m2a); nsB = symB_of(m2b); fetch(t + 4, m2a, m2b); }
         else { nsA = rsA[t + 2]; nsB = rsB[t + 2]; }
@@ -534,6 +547,8 @@ void pmx_sw16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict
         const unsigned rA = g * R + kA, rB = g * R + kB;
         keyA = ((unsigned long long)sA << 32) | ((0xFFFFu - cA) << 16) | (0xFFFFu - rA);
         keyB = ((unsigned long long)sB << 32) | ((0xFFFFu - cB) << 16) | (0xFFFFu - rB);
+        if (fake & 0xFFFF) keyA = 0;            // a bound taken over from the group, never reached by this lane
+        if (fake >> 16) keyB = 0;
     }
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1) {
