@@ -45,8 +45,9 @@ def make_cfg2_inputs(n=N_PAIRS, seed=wl.CFG2["seed"]):
 # SIMD, a 32-bit-encoded VOP2 (v_add_u32, v_sub_u32) 2 cycles.  Counted inner-loop instructions per 2 cells x 64
 # lanes (= 128 cells), by kernel family: (VOP3, VOP2, what).
 VALU_MODEL = {
-    "pmx_sw16_kernel": (5.5, 3.0, "sw16 skewed max3+vop2 variant: 5.5 VOP3/VOP3P + 3 VOP2 per 128 cells"),
-    "pmx_sw16q_kernel": (5.5, 3.0, "sw16q (shared profile): 5.5 VOP3/VOP3P + 3 VOP2 per 128 cells"),
+    "pmx_sw16_kernel": (4.5, 3.0, "sw16 skewed max3+vop2 variant: 4.5 VOP3/VOP3P + 3 VOP2 per 128 cells in steps that improve no lane's best "
+                                  "(+1 v_bfi_b32 per 128 cells in the steps that do: the end-position strip save, data-dependent since round 2)"),
+    "pmx_sw16q_kernel": (4.5, 3.0, "sw16q (shared profile): 4.5 VOP3/VOP3P + 3 VOP2 per 128 cells in steps that improve no lane's best (+1 in those that do)"),
     "pmx_stats16p_kernel": (30.0, 4.0, "stats16p: score arithmetic 7 + nine statistic planes moved by v_bfi_b32 under sign masks"),
     "pmx_stats16c_kernel": (17.0, 4.0, "stats16c: score arithmetic 7 + one combined statistics word per H/E/F moved by v_cndmask"),
     "pmx_nwsg16v_kernel/packed trace": (12.25, 3.0, "nwsg16v + traceback: score 4 VOP3 + 3 VOP2, 4 packed differences + 3.5 v_bfi merges + 0.75 v_perm per 128 cells"),

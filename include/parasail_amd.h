@@ -372,6 +372,8 @@ const char *pmx_version(void);
 const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen, int32_t max_rlen);
 /* Name (with template shape and arithmetic variant) of the kernel the calling thread's last batch call launched. */
 const char *pmx_last_kernel(void);
+/* Every environment switch the library reads, one "NAME\tkind\twhat\n" line each (parasail-rs_amd/csrc/pmx_switches.h). */
+const char *pmx_switches(void);
 
 #ifdef __cplusplus
 }

@@ -114,6 +114,7 @@ _sig("pmx_device_count", C.c_int)
 _sig("pmx_set_device", C.c_int, C.c_int)
 _sig("pmx_kernel_for", C.c_char_p, C.POINTER(pmx_config_t), C.c_int32, C.c_int32)
 _sig("pmx_last_kernel", C.c_char_p)
+_sig("pmx_switches", C.c_char_p)
 _sig("pmx_align_batch", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
      C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("pmx_align_batch_device", C.c_int, C.POINTER(pmx_config_t), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -919,6 +920,11 @@ def _record_buffer(out, n):
     if out.dtype != RECORD_DTYPE or out.shape != (n,) or not out.flags.c_contiguous:
         raise BatchError("out must be a contiguous RECORD_DTYPE array of %d records" % n)
     return out
+
+
+def switches():
+    """[(name, kind, what)] for every environment switch the library reads (csrc/pmx_switches.h)."""
+    return [tuple(line.split("\t")) for line in lib.pmx_switches().decode().splitlines()]
 
 
 def host_register(*arrays):

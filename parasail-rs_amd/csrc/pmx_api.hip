@@ -6,6 +6,7 @@
 // All DP arithmetic is done by the HIP kernels (pmx_sw16.hip, pmx_general.hip); this file
 // owns handles, dispatch-name parsing, device staging and result marshalling only.
 #include "pmx_common.h"
+#include "pmx_switches.h"
 #include <chrono>
 #include <future>
 #include "pmx_matrices.h"
@@ -23,6 +24,30 @@
 #include <unordered_map>
 #include <utility>
 #include <vector>
+
+// ---- the switch table (pmx_switches.h) ------------------------------------------------------------------------------
+static const PmxSwitchDoc g_switches[] = {
+#define X(name, kind, what) {name, kind, what},
+    PMX_SWITCH_TABLE(X)
+#undef X
+};
+const char *pmx_env(const char *name)
+{
+    for (const PmxSwitchDoc &d : g_switches)
+        if (!strcmp(d.name, name)) return getenv(name);
+    fprintf(stderr, "libparasail_amd: environment switch %s is not in pmx_switches.h\n", name);
+    abort();
+}
+// "NAME\tkind\twhat\n" per switch (static storage)
+extern "C" const char *pmx_switches(void)
+{
+    static const std::string text = []() {
+        std::string t;
+        for (const PmxSwitchDoc &d : g_switches) { t += d.name; t += '\t'; t += d.kind; t += '\t'; t += d.what; t += '\n'; }
+        return t;
+    }();
+    return text.c_str();
+}
 
 // ============================================================================ errors ====
 static thread_local char g_err[512] = "";
@@ -154,7 +179,7 @@ static const parasail_matrix_t *lookup_in_matrix_dir(const std::string &lname)
     std::lock_guard<std::mutex> lk(mx);
     auto it = cache.find(lname);
     if (it != cache.end()) return it->second;
-    const char *dir = getenv("PMX_MATRIX_DIR");
+    const char *dir = pmx_env("PMX_MATRIX_DIR");
     if (!dir || !*dir) return nullptr;
     parasail_matrix_t *m = nullptr;
     for (const char *suffix : {"", ".txt", ".mat"}) {
@@ -1139,14 +1164,14 @@ static int trace_ws_init()
 static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch &b,
                                  pmx_record_t *d_out, pmx_stats_t *d_stats, hipStream_t st)
 {
-    if (getenv("PMX_NO_STATS_BY_TRACE")) return 1;
+    if (pmx_env("PMX_NO_STATS_BY_TRACE")) return 1;
     int variant = 0, Tmax = 0, G = 0, R = 0; size_t tbytes = 0;
     if (pmx_nwsgq_trace_plan(b, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes, &G, &R) != 0) return 1;
     if (trace_ws_init()) return -1;
     const long long NP = 2 * (64 / G) * 4;                     // pairs per workgroup of the sweep
     double chunk_bytes = 40e9;                                 // (measured on cfg 3: 8 GB chunks 55.0 ms, 24 GB 53.1 ms, 40 GB 51.0 ms)
     { size_t fb = 0, tb = 0; if (hipMemGetInfo(&fb, &tb) == hipSuccess && 0.2 * (double)fb < chunk_bytes) chunk_bytes = 0.2 * (double)fb; }
-    if (const char *e = getenv("PMX_STATS_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
+    if (const char *e = pmx_env("PMX_STATS_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
     const double per_pair = (double)tbytes / (double)b.n;
     long long chunk = (long long)(chunk_bytes / per_pair) / NP * NP;
     if (chunk < NP) chunk = NP;
@@ -1276,7 +1301,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
     // (shared profile, or per-pair over a large alphabet, no free end); (2) large alphabets with short references: traceback
     // again; (3) the unpacked statistics kernel
     if (q_shared && want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&
-        (cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && (n >= 512 || getenv("PMX_STATS_BY_TRACE"))) {
+        (cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && (n >= 512 || pmx_env("PMX_STATS_BY_TRACE"))) {
         // profile arm with statistics (BASELINE config 3): traceback sweep + counting walk
         const int rc = stats_by_trace_shared(cfg, dm, b, d_out, d_stats_out, st);
         if (rc < 0) return rc;
@@ -1290,10 +1315,10 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
                 if (rc < 0) { set_err("stats16p launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
                 if (rc == 0) return 0;
             }
-            if (!(dm.d.msize > 8 && (max_rlen <= 1024 || getenv("PMX_STATS_BY_TRACE_ANY")))) break;
+            if (!(dm.d.msize > 8 && (max_rlen <= 1024 || pmx_env("PMX_STATS_BY_TRACE_ANY")))) break;
         }
         if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE &&
-            (dm.d.msize <= 8 || pass == 1) && !q_shared && (n >= 2048 || getenv("PMX_STATS_BY_TRACE")) && !getenv("PMX_NO_STATS_BY_TRACE")) {
+            (dm.d.msize <= 8 || pass == 1) && !q_shared && (n >= 2048 || pmx_env("PMX_STATS_BY_TRACE")) && !pmx_env("PMX_NO_STATS_BY_TRACE")) {
             // (a few pairs: the one-pass statistics kernel has the lower latency)
             // Small alphabets: statistics = counts along the traceback path (the same decisions and tie-breaks as the
             // coupled statistics tables).  The packed traceback sweep runs at more than twice the speed of the
@@ -1747,7 +1772,7 @@ static int cigar_device_run(const pmx_config_t *cfg, const DevMat &dm, int64_t n
     // fewer launch tails), at most 15 % of the free HBM each, at least two for the overlap once the batch is worth it
     double chunk_bytes = 12e9;
     { size_t fb = 0, tb = 0; if (hipMemGetInfo(&fb, &tb) == hipSuccess && 0.15 * (double)fb < chunk_bytes) chunk_bytes = 0.15 * (double)fb; }
-    if (const char *e = getenv("PMX_CIGAR_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
+    if (const char *e = pmx_env("PMX_CIGAR_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
     int64_t nchunks = (int64_t)((double)tbytes / chunk_bytes) + 1;
     if (nchunks < 2 && n >= 16384) nchunks = 2;
     int64_t chunk = ((n + nchunks - 1) / nchunks + 63) / 64 * 64;
@@ -1756,7 +1781,7 @@ static int cigar_device_run(const pmx_config_t *cfg, const DevMat &dm, int64_t n
     size_t cbytes = 0;
     (void)pmx_trace16_plan(bc, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &cbytes);
     cbytes = (cbytes + 255) & ~(size_t)255;
-    const bool two = chunk < n && !getenv("PMX_CIGAR_NO_OVERLAP");     // (diagnostics: sweep and walk back to back on one stream)
+    const bool two = chunk < n && !pmx_env("PMX_CIGAR_NO_OVERLAP");     // (diagnostics: sweep and walk back to back on one stream)
     uint32_t *tbuf = nullptr, *dops = nullptr; unsigned char *misc = nullptr;
     const size_t scan_bytes = pmx_text_scan_scratch_bytes(n);
     const size_t misc_bytes = (size_t)(4 * n + 2) * sizeof(int32_t) + 256 + scan_bytes;
@@ -1836,7 +1861,7 @@ struct TextBuf {
 struct StageTimer {
     bool on; double t0; const char *what;
     static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
-    StageTimer() : on(getenv("PMX_TIMING") != nullptr), t0(now()), what("") {}
+    StageTimer() : on(pmx_env("PMX_TIMING") != nullptr), t0(now()), what("") {}
     void done(const char *stage) { if (on) { (void)hipDeviceSynchronize(); const double t = now(); fprintf(stderr, "[pmx timing] %-28s %8.3f ms\n", stage, (t - t0) * 1e3); t0 = t; } }
 };
 
@@ -2066,7 +2091,7 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && 0.45 * (double)free_b < chunk_bytes) chunk_bytes = 0.45 * (double)free_b;
     }
-    if (const char *e = getenv("PMX_CIGAR_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
+    if (const char *e = pmx_env("PMX_CIGAR_CHUNK_BYTES")) chunk_bytes = atof(e);      // tests force small chunks
     // equal shares: as many chunks as the budget needs, each with about the same number of table bytes
     double total_bytes = 0;
     for (int64_t k = 0; k < n; ++k) total_bytes += 1.0 * (double)(qoff[k + 1] - qoff[k] + 64) * (double)(roff[k + 1] - roff[k] + 64);

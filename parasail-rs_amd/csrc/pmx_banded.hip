@@ -14,6 +14,7 @@
 // way round (above from lane x+1) -- one DPP shift of (H, E) or (H, F) per step, no scan along the row.
 // 32-bit lanes (no saturation inside a band), score + end positions with the oracle's rules for every mode.
 #include "pmx_common.h"
+#include "pmx_switches.h"
 
 #define B_NEG (INT32_MIN / 2)
 
@@ -173,7 +174,7 @@ int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMat
 {
     (void)max_qlen; (void)max_rlen;
     if (n <= 0) return 0;
-    if (getenv("PMX_NO_FAST_BANDED")) return 1;
+    if (pmx_env("PMX_NO_FAST_BANDED")) return 1;
     if (m.msize > PMX_MAX_FAST_MSIZE || band > 63) return 1;       // wider bands: the general kernel masks instead
 #define LB(LP) hipLaunchKernelGGL((pmx_banded_kernel<LP>), dim3((unsigned)((n + 64 / LP - 1) / (64 / LP))), dim3(64), 0, stream, \
                                   qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, mode, sg_flags, open, ext, band, diag, out)

@@ -25,6 +25,7 @@
 //     maximum of the last row (reference end free) and of the last column (query end free; last column
 //     wins only if strictly greater -- oracle/pmx_oracle.c states the rule).
 #include "pmx_common.h"
+#include "pmx_switches.h"
 #include <cstdlib>
 
 typedef short v2s __attribute__((ext_vector_type(2)));
@@ -1376,7 +1377,7 @@ template <int G, int R, bool TR = false, bool FETCH = false, bool TRB = false>
 static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
                         pmx_record_t *d_out, hipStream_t stream, uint32_t *tbuf = nullptr, int Tmax = 0)
 {
-    if (TR && !TRB && (m.max > 0 ? m.max : 0) + 2 * open <= 250 && !getenv("PMX_TRACE_NO_BFI"))     // bounded differences: the one-instruction merge
+    if (TR && !TRB && (m.max > 0 ? m.max : 0) + 2 * open <= 250 && !pmx_env("PMX_TRACE_NO_BFI"))     // bounded differences: the one-instruction merge
         return launch_nwsgv<G, R, TR, FETCH, TR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     constexpr int RS = (R + 3) / 4 * 4, NP = 2 * (64 / G);
     const int RP = ((b.max_rlen + 2 * (G - 1) + 4 + 7) / 4) * 4;
@@ -1400,7 +1401,7 @@ static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
 // the skew growth must fit the exact window with the bias chosen here.  Returns the bias, or 0.
 int pmx_nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext)
 {
-    if (getenv("PMX_NWSG16_GEN1")) return 0;
+    if (pmx_env("PMX_NWSG16_GEN1")) return 0;
     if (m.msize > PMX_MAX_FAST_MSIZE - 1 || open < ext || ext < 0 || b.max_rlen > 30000) return 0;
     const long long lo = -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
     const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);
@@ -1417,7 +1418,7 @@ int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
 {
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
     if (b.q_shared || b.perm || !pmx_nwsgv_bias(b, m, open, ext)) return 1;
-    if (m.msize > 8 && m.msize < 32 && !getenv("PMX_NWSG16_NO_MATRIX_LOOKUP")) {   // large alphabet: the matrix-lookup kernel (1 KB of LDS)
+    if (m.msize > 8 && m.msize < 32 && !pmx_env("PMX_NWSG16_NO_MATRIX_LOOKUP")) {   // large alphabet: the matrix-lookup kernel (1 KB of LDS)
         int G = 0;
         for (int v = 1; v < 4 && !G; ++v) if (b.max_qlen <= (8 << v) * 16 - 1) { *variant = 4 + v; G = 8 << v; }
         if (!G) return 1;
@@ -1449,7 +1450,7 @@ int pmx_launch_nwsgv_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m
     case 6: return launch_nwsgm<32, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 7: return launch_nwsgm<64, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 0: return launch_nwsgv<8, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
-    case 1: if (getenv("PMX_TRACE_FETCH")) return launch_nwsgv<16, 16, true, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 1: if (pmx_env("PMX_TRACE_FETCH")) return launch_nwsgv<16, 16, true, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
             return launch_nwsgv<16, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 2: return launch_nwsgv<32, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 3: return launch_nwsgv<64, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
@@ -1461,7 +1462,7 @@ int pmx_launch_nwsgv_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m
 int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                       pmx_record_t *d_out, hipStream_t stream, const char **kernel_name)
 {
-    if (getenv("PMX_NO_FAST_NWSG")) return 1;
+    if (pmx_env("PMX_NO_FAST_NWSG")) return 1;
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
     if (m.msize > PMX_MAX_FAST_MSIZE - 1) return 1;
     if (open < ext || open < 0 || ext < 0) return 1;           // the virtual-row/column fixed points need open >= extend
@@ -1471,7 +1472,7 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
     // (second generation, scores only: the row above lane 0 is a closed form, so no virtual row is needed and the
     //  query may fill all G * R rows; the first generation and the traceback walk need row -1 to exist)
     if (const int nb = pmx_nwsgv_bias(b, m, open, ext)) {
-        if (b.q_shared && !getenv("PMX_NWSG16_NO_SHARED")) {        // profile arm: one profile per workgroup, references from HBM
+        if (b.q_shared && !pmx_env("PMX_NWSG16_NO_SHARED")) {        // profile arm: one profile per workgroup, references from HBM
 #define TRYQ(GG, RR, NAME)                                                      \
             if (q <= (GG) * (RR)) {                                         \
                 int rc = launch_nwsgq<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
@@ -1485,7 +1486,7 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
             TRYQ(64, 32, "pmx_nwsg16q_kernel<64,32>/shared profile")
 #undef TRYQ
         }
-        if (!b.q_shared && m.msize > 8 && m.msize < 32 && b.n > 2048 && !getenv("PMX_NWSG16_NO_MATRIX_LOOKUP")) {   // per-pair, large alphabet
+        if (!b.q_shared && m.msize > 8 && m.msize < 32 && b.n > 2048 && !pmx_env("PMX_NWSG16_NO_MATRIX_LOOKUP")) {   // per-pair, large alphabet
 #define TRYM(GG, RR, NAME)                                                      \
             if (q <= (GG) * (RR)) {                                             \
                 int rc = launch_nwsgm<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
@@ -1498,7 +1499,7 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
             TRYM(64, 16, "pmx_nwsg16m_kernel<64,16>/matrix lookup")
 #undef TRYM
         }
-        const bool longref = b.max_rlen >= 1024 && !getenv("PMX_NWSG16_NO_FETCH");   // staged references would dominate the LDS
+        const bool longref = b.max_rlen >= 1024 && !pmx_env("PMX_NWSG16_NO_FETCH");   // staged references would dominate the LDS
 #define TRYV(GG, RR, NAME)                                                      \
         if (q <= (GG) * (RR)) {                                             \
             int rc = longref ? launch_nwsgv<GG, RR, false, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream) \

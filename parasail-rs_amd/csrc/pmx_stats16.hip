@@ -17,6 +17,7 @@
 //     (score -inf + F chain when penalised, score 0 + diagonal when free; length increments are
 //     switched off on virtual columns).  Needs open >= extend >= 1.
 #include "pmx_common.h"
+#include "pmx_switches.h"
 #include <cstdlib>
 
 #define SB 32768
@@ -353,7 +354,7 @@ static int launch_stats(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
 int pmx_launch_stats16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                        pmx_record_t *d_out, pmx_stats_t *d_stats, hipStream_t stream, const char **kernel_name)
 {
-    if (getenv("PMX_NO_FAST_STATS")) return 1;
+    if (pmx_env("PMX_NO_FAST_STATS")) return 1;
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG && mode != PMX_MODE_SW) return 1;
     if (m.msize > PMX_MAX_FAST_MSIZE - 1) return 1;
     if (ext < 1 || open < ext || open > 4096) return 1;

@@ -18,6 +18,7 @@
 //   * match / similar increments come from two more byte planes of the LDS profile.  With a shared query
 //     (profile arm) the planes are built once per 4-wave workgroup.
 #include "pmx_common.h"
+#include "pmx_switches.h"
 #include <cstdlib>
 
 typedef short p_v2s __attribute__((ext_vector_type(2)));
@@ -401,15 +402,15 @@ static int launch_statsp(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
 int pmx_launch_stats16p(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                         pmx_record_t *d_out, pmx_stats_t *d_stats, hipStream_t stream, const char **kernel_name)
 {
-    if (getenv("PMX_NO_FAST_STATS") || getenv("PMX_STATS16_GEN1")) return 1;
+    if (pmx_env("PMX_NO_FAST_STATS") || pmx_env("PMX_STATS16_GEN1")) return 1;
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
     // Where it pays (measured): one shared query profile per workgroup (the profile arm, config 3) and results that
     // are captured once per pair (no free end: nw, sg_qb, sg_db, sg_qb_db).  Per-pair profiles cost too much LDS
     // in three planes, and per-step last-row / last-column captures are cheaper in the unpacked kernel.
     // Per-pair queries: only over large alphabets, with the matrix-lookup variant (no profile planes).
-    const bool ml = !b.q_shared && m.msize > 8 && m.msize < 32 && !getenv("PMX_STATS16P_NO_MATRIX_LOOKUP");
-    if (!b.q_shared && !ml && !getenv("PMX_STATS16P_ALWAYS")) return 1;
-    if (mode == PMX_MODE_SG && (sg_flags & (PMX_SG_QE | PMX_SG_DE)) && !getenv("PMX_STATS16P_ALWAYS")) return 1;
+    const bool ml = !b.q_shared && m.msize > 8 && m.msize < 32 && !pmx_env("PMX_STATS16P_NO_MATRIX_LOOKUP");
+    if (!b.q_shared && !ml && !pmx_env("PMX_STATS16P_ALWAYS")) return 1;
+    if (mode == PMX_MODE_SG && (sg_flags & (PMX_SG_QE | PMX_SG_DE)) && !pmx_env("PMX_STATS16P_ALWAYS")) return 1;
     if (ext < 1 || b.max_qlen + b.max_rlen + 2 > 32767) return 1;          // statistics live in int16 halves
     const int nb = pmx_nwsgv_bias(b, m, open, ext);                         // same window proof as the score kernel
     if (!nb) return 1;

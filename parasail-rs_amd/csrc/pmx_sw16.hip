@@ -37,6 +37,7 @@
 // profile row is -32768 (H falls to zero, gaps only decay), padded query rows score 0; neither
 // can strictly exceed the true maximum nor precede its first occurrence in column-major order.
 #include "pmx_common.h"
+#include "pmx_switches.h"
 #include <cstdlib>
 
 typedef short v2s __attribute__((ext_vector_type(2)));
@@ -622,7 +623,7 @@ static int launch_one(const PmxBatch &b, const PmxDevMatrix &m, int open, int ex
 // 16 rows per lane; eligible exactly when that variant would be chosen for scores (so no re-run flag can occur).
 static bool sw16_trace_ok(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext)
 {
-    if (getenv("PMX_TRACE16_GEN1") || getenv("PMX_SW16_NO_SKEW") || getenv("PMX_SW16_NO_U8") || getenv("PMX_SW16_VARIANT")) return false;
+    if (pmx_env("PMX_TRACE16_GEN1") || pmx_env("PMX_SW16_NO_SKEW") || pmx_env("PMX_SW16_NO_U8") || pmx_env("PMX_SW16_VARIANT")) return false;
     if (m.msize > PMX_MAX_FAST_MSIZE || open < ext || ext < 0 || open > 1024 || b.max_rlen > 30000 || b.q_shared || b.perm) return false;
     if (m.min < -1024 || m.max > 2048 || m.min + open < 0 || open + ext > 1024 || m.max + open > 255) return false;
     const long long feasible = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0);
@@ -631,7 +632,7 @@ static bool sw16_trace_ok(const PmxBatch &b, const PmxDevMatrix &m, int open, in
 int pmx_sw16_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, int *variant, int *Tmax, size_t *trace_bytes)
 {
     if (!sw16_trace_ok(b, m, open, ext)) return 1;
-    if (m.msize > 8 && m.msize < 32 && !getenv("PMX_SW16_NO_MATRIX_LOOKUP")) {     // large alphabet: the matrix-lookup kernel (no profile, 1 KB of LDS)
+    if (m.msize > 8 && m.msize < 32 && !pmx_env("PMX_SW16_NO_MATRIX_LOOKUP")) {     // large alphabet: the matrix-lookup kernel (no profile, 1 KB of LDS)
         int G = 0;
         for (int v = 1; v < 4 && !G; ++v) if (b.max_qlen <= (8 << v) * 16) { *variant = 4 + v; G = 8 << v; }
         if (!G) return 1;
@@ -675,31 +676,31 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
     if (b.max_rlen > 60000) return 1;                 // 16-bit column index
     const int q = b.max_qlen;
     // max3 variant: gap penalties and the most negative score must keep every live value >= 1024
-    const char *force = getenv("PMX_SW16_VARIANT");
+    const char *force = pmx_env("PMX_SW16_VARIANT");
     int var = 0;
     if (open <= 1024 && ext <= 1024 && m.min >= -1024 && m.max <= 2048) var = 1;
     // 32-bit add/sub variant: score + open must be non-negative, and E - extend must not borrow
     if (var == 1 && m.min + open >= 0 && open + ext <= 1024) var = 2;
     if (force && atoi(force) < var) var = atoi(force);
-    const bool u8ok = var == 2 && m.max + open <= 255 && !getenv("PMX_SW16_NO_U8");
+    const bool u8ok = var == 2 && m.max + open <= 255 && !pmx_env("PMX_SW16_NO_U8");
     // column-skewed variant: values grow by (columns + 2 G + 4) * ext; use it only when no feasible
     // score can reach the correspondingly lower re-run limit
     const long long feasible = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0);
-    const bool sk = var == 2 && open >= ext && !getenv("PMX_SW16_NO_SKEW") &&
+    const bool sk = var == 2 && open >= ext && !pmx_env("PMX_SW16_NO_SKEW") &&
                     feasible + M3_BIAS < (long long)M3_LIMIT(m.max) - (long long)(b.max_rlen + 2 * 64 + 4) * ext;
     // alphabets of <= 4 letters (+ wildcard): no LDS profile, the v_perm looks the score up (see PT in the kernel)
-    const bool pt = sk && u8ok && m.msize <= 5 && b.retry_list && b.retry_count && !b.q_has_wildcard && !getenv("PMX_SW16_NO_PERMTABLE");
+    const bool pt = sk && u8ok && m.msize <= 5 && b.retry_list && b.retry_count && !b.q_has_wildcard && !pmx_env("PMX_SW16_NO_PERMTABLE");
     // one shared query (profile arm) with a real LDS profile: the workgroup-shared-profile kernel (pmx_sw16q.hip)
     if (b.q_shared && var == 2 && u8ok && sk && !pt) {
         const int rc = pmx_launch_sw16q(b, m, open, ext, d_out, stream, kernel_name);
         if (rc <= 0) return rc;
     }
     // per-pair queries over a large alphabet: no LDS profile at all, the scores are read from the matrix (pmx_sw16m.hip)
-    if (!b.q_shared && var == 2 && u8ok && sk && !pt && (m.msize > 8 || getenv("PMX_SW16_MATRIX_LOOKUP")) && b.n > 2048) {
+    if (!b.q_shared && var == 2 && u8ok && sk && !pt && (m.msize > 8 || pmx_env("PMX_SW16_MATRIX_LOOKUP")) && b.n > 2048) {
         const int rc = pmx_launch_sw16m(b, m, open, ext, d_out, stream, kernel_name);
         if (rc <= 0) return rc;
     }
-    const bool longref = b.max_rlen >= 1024 && !getenv("PMX_SW16_NO_FETCH");     // staged references would dominate the LDS
+    const bool longref = b.max_rlen >= 1024 && !pmx_env("PMX_SW16_NO_FETCH");     // staged references would dominate the LDS
 #define TRY(GG, RR, NAME)                                                       \
     if (q <= (GG) * (RR)) {                                                     \
         constexpr int R4 = (RR);            /* byte-profile rows are reserved in whole dwords: any R */ \
@@ -712,7 +713,7 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                : var == 2 ? launch_one<GG, RR, 2>(b, m, open, ext, d_out, stream)  \
                : var == 1 ? launch_one<GG, RR, 1>(b, m, open, ext, d_out, stream)  \
                           : launch_one<GG, RR, 0>(b, m, open, ext, d_out, stream); \
-        if (rc <= 0) { if (kernel_name) *kernel_name = pt ? NAME "/max3+vop2+skew+permtable" : var == 2 ? (sk ? NAME "/max3+vop2+skew" : NAME "/max3+vop2") : var == 1 ? NAME "/max3" : NAME; return rc; } \
+        if (rc <= 0) { if (kernel_name) *kernel_name = pt ? NAME "/max3+vop2+skew+permtable" : var == 2 ? (sk ? ((u8 && longref) ? NAME "/max3+vop2+u8+skew+fetch" : NAME "/max3+vop2+skew") : NAME "/max3+vop2") : var == 1 ? NAME "/max3" : NAME; return rc; } \
     }
     // byte profile, 8 lanes per pair: half the fill/drain and per-step overhead of <16,10> at the same LDS;
     // rows per lane chosen for the common read lengths (100, 125, 150) so that few rows are padding

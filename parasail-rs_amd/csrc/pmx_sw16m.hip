@@ -10,6 +10,7 @@
 // (column-skewed values, v_pk_maximum3_f16 as integer max3, VOP2 add/sub) and results are those of
 // pmx_sw16.hip's skewed variants.
 #include "pmx_common.h"
+#include "pmx_switches.h"
 #include <cstdlib>
 
 typedef short m_v2s __attribute__((ext_vector_type(2)));
@@ -300,7 +301,7 @@ int pmx_launch_sw16m_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m
 int pmx_launch_sw16m(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                      pmx_record_t *d_out, hipStream_t stream, const char **kernel_name)
 {
-    if (b.q_shared || m.msize > 31 || getenv("PMX_SW16_NO_MATRIX_LOOKUP")) return 1;
+    if (b.q_shared || m.msize > 31 || pmx_env("PMX_SW16_NO_MATRIX_LOOKUP")) return 1;
     const int q = b.max_qlen;
 #define TRYM(GG, RR, NAME)                                                      \
     if (q <= (GG) * (RR)) {                                                     \

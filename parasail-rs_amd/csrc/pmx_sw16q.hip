@@ -11,6 +11,7 @@
 //     (neighbouring lanes read neighbouring bytes).  16 references of 5 kaa would otherwise take 80 KB.
 // LDS drops from 57 KB per wave to 11 KB per workgroup, the occupancy from 0.5 to 4 waves per SIMD.
 #include "pmx_common.h"
+#include "pmx_switches.h"
 #include <cstdlib>
 
 typedef short q_v2s __attribute__((ext_vector_type(2)));
@@ -249,7 +250,7 @@ static int launch_q(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
 int pmx_launch_sw16q(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
                      pmx_record_t *d_out, hipStream_t stream, const char **kernel_name)
 {
-    if (!b.q_shared || getenv("PMX_SW16_NO_SHARED")) return 1;
+    if (!b.q_shared || pmx_env("PMX_SW16_NO_SHARED")) return 1;
     const int q = b.max_qlen;
 #define TRYQ(GG, RR, NAME)                                                      \
     if (q <= (GG) * (RR)) {                                                     \

@@ -1,0 +1,47 @@
+// pmx_switches.h -- every environment switch of the library, in one table.
+//
+// The dispatcher picks one implementation per call from the shapes and the scoring; a switch overrides one of those choices.
+// All alternatives produce identical results: tests/test_gpu_switches.py runs a fixed set of batches under every "force" switch
+// listed here (it reads the table through pmx_switches()) and compares the records with the unswitched run, and the A/B scripts under
+// profiles/ use them to time one alternative against another.  Nothing else in the library reads the environment.
+// The environment is read at every call (tests flip switches between calls); a lookup costs ~50 ns.
+#pragma once
+#include <cstdlib>
+
+struct PmxSwitchDoc { const char *name, *kind, *what; };
+
+// kind: "force" = boolean, forces an alternative implementation; "value" = numeric parameter; "path"; "diag" = diagnostics output
+#define PMX_SWITCH_TABLE(X) \
+    X("PMX_MATRIX_DIR",               "path",  "directory of NCBI-format matrix files for names that are not built in (parasail_matrix_lookup)") \
+    X("PMX_SW16_VARIANT",             "value", "local kernels: highest arithmetic variant allowed (0 saturating int16, 1 max3, 2 max3 + 32-bit add/sub)") \
+    X("PMX_SW16_NO_U8",               "force", "local kernels: int16 profile entries instead of bytes") \
+    X("PMX_SW16_NO_SKEW",             "force", "local kernels: no column skew (E extension with a subtract)") \
+    X("PMX_SW16_NO_PERMTABLE",        "force", "local kernels, alphabets of <= 4 letters: LDS profile instead of the v_perm score table") \
+    X("PMX_SW16_NO_SHARED",           "force", "local, profile arm: per-pair profiles instead of the workgroup-shared profile kernel") \
+    X("PMX_SW16_NO_MATRIX_LOOKUP",    "force", "local, large alphabets: LDS profiles instead of the matrix-lookup kernel") \
+    X("PMX_SW16_MATRIX_LOOKUP",       "force", "local: matrix-lookup kernel also for small alphabets") \
+    X("PMX_SW16_NO_FETCH",            "force", "local, references >= 1024: stage references in LDS instead of fetching them two steps ahead") \
+    X("PMX_NO_FAST_NWSG",             "force", "global / semi-global: general int32 kernel instead of the packed int16 kernels") \
+    X("PMX_NWSG16_GEN1",              "force", "global / semi-global: first-generation packed kernel") \
+    X("PMX_NWSG16_NO_SHARED",         "force", "global / semi-global, profile arm: per-pair profiles instead of the shared-profile kernel") \
+    X("PMX_NWSG16_NO_MATRIX_LOOKUP",  "force", "global / semi-global, large alphabets: LDS profiles instead of the matrix-lookup kernel") \
+    X("PMX_NWSG16_NO_FETCH",          "force", "global / semi-global, references >= 1024: stage references in LDS") \
+    X("PMX_NO_FAST_STATS",            "force", "statistics: general kernel instead of the packed statistics kernels") \
+    X("PMX_STATS16_GEN1",             "force", "statistics: first-generation statistics kernel instead of stats16p") \
+    X("PMX_STATS16P_ALWAYS",          "force", "statistics: stats16p also where statistics by traceback would be chosen") \
+    X("PMX_STATS16P_NO_MATRIX_LOOKUP","force", "statistics, large alphabets: LDS profiles instead of the matrix lookup") \
+    X("PMX_STATS_BY_TRACE",           "force", "statistics by traceback also for small batches") \
+    X("PMX_STATS_BY_TRACE_ANY",       "force", "statistics by traceback also for large alphabets with long references") \
+    X("PMX_NO_STATS_BY_TRACE",        "force", "statistics: never by traceback (statistics-carrying kernels)") \
+    X("PMX_STATS_CHUNK_BYTES",        "value", "statistics by traceback: bytes of trace scratch per chunk (tests force several chunks)") \
+    X("PMX_NO_FAST_TRACE",            "force", "traceback: general kernel (1 byte per cell) instead of the packed 4-bit kernels") \
+    X("PMX_TRACE16_GEN1",             "force", "traceback: first-generation packed kernel and one-lane walk") \
+    X("PMX_TRACE_NO_BFI",             "force", "traceback: three-instruction decision merge instead of the bounded-difference v_bfi merge") \
+    X("PMX_TRACE_FETCH",              "force", "traceback <16,16>: fetch references from HBM instead of staging them") \
+    X("PMX_CIGAR_CHUNK_BYTES",        "value", "batch CIGAR: bytes of trace scratch per chunk (tests force several chunks)") \
+    X("PMX_CIGAR_NO_OVERLAP",         "force", "batch CIGAR: sweep and walk back to back on one stream (no double buffering)") \
+    X("PMX_NO_FAST_BANDED",           "force", "banded: general kernel with a band mask instead of the band-only kernel") \
+    X("PMX_NO_FAST_TABLE",            "force", "score tables: general kernel instead of the table kernel") \
+    X("PMX_TIMING",                   "diag",  "stage times of the batch CIGAR host entry on stderr")
+
+const char *pmx_env(const char *name);        // the environment value of a registered switch (pmx_api.hip; an unregistered name aborts)

@@ -16,6 +16,7 @@
 //     (closing and reopening a gap never beats extending it), which the reference asks for (src/aligner/mod.rs:139-153).
 //   * 32-bit lanes: no saturation, every mode (nw / sg with any free ends / sw), end positions with the oracle's rules.
 #include "pmx_common.h"
+#include "pmx_switches.h"
 #include <cstdlib>
 
 #define TNEG (INT32_MIN / 2)
@@ -210,7 +211,7 @@ int pmx_launch_table(int mode, int sg_flags, int open, int ext, const PmxDevMatr
                      pmx_record_t *out, hipStream_t stream)
 {
     if (n <= 0) return 0;
-    if (getenv("PMX_NO_FAST_TABLE")) return 1;
+    if (pmx_env("PMX_NO_FAST_TABLE")) return 1;
     if (open < ext || ext < 0 || m.msize > PMX_MAX_FAST_MSIZE || max_rlen > 64 * 16 || max_qlen > 100000) return 1;
     if (!tab_off && n > 1 && table) return 1;
     const size_t lds = (((size_t)m.msize * m.msize * 2 + 15) & ~(size_t)15) + (size_t)max_qlen + 16 + (max_rlen > 256 ? 4096 : 0);

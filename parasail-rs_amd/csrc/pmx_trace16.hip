@@ -21,6 +21,7 @@
 //   * pmx_walk16_kernel (one lane per pair) walks the nibbles from the captured end position and
 //     emits run-length BAM ops.
 #include "pmx_common.h"
+#include "pmx_switches.h"
 #include <cstdlib>
 
 #define TB 32768                 // bias of the u16 lanes
@@ -472,12 +473,12 @@ static int launch_trace(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
 int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
                      int *variant, int *Tmax, size_t *trace_bytes, bool packed_ok)
 {
-    if (getenv("PMX_NO_FAST_TRACE")) return 1;
+    if (pmx_env("PMX_NO_FAST_TRACE")) return 1;
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG && mode != PMX_MODE_SW) return 1;
     if (m.msize > PMX_MAX_FAST_MSIZE - 1) return 1;
     if (open < ext || open < 0 || ext < 0 || open > 4096) return 1;
     if (b.max_rlen > 30000 || b.q_shared) return 1;
-    if (packed_ok && !getenv("PMX_TRACE16_GEN1") && pmx_nwsgv_trace_plan(b, m, mode, open, ext, variant, Tmax, trace_bytes) == 0) {
+    if (packed_ok && !pmx_env("PMX_TRACE16_GEN1") && pmx_nwsgv_trace_plan(b, m, mode, open, ext, variant, Tmax, trace_bytes) == 0) {
         *variant += 10;            // packed traceback of the second-generation nw/sg kernel
         return 0;
     }

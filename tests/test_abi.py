@@ -237,3 +237,19 @@ def test_matrix_lookup_resolves_documented_names_from_a_directory(pkg, tmp_path,
     for bad in ("blosum45", "../blosum50", "/etc/passwd", ""):
         with pytest.raises((pkg.FailedLookup, pkg.PanicError)):
             pkg.Matrix.from_name(bad)
+
+
+def test_environment_switches_are_tabled(pkg):
+    """The library reads the environment only through pmx_env(), and only names listed in csrc/pmx_switches.h (which
+    tests/test_gpu_switches.py sweeps on the GPU): no stray getenv, no unlisted or unused switch."""
+    import glob
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "parasail-rs_amd", "csrc")
+    table = pkg.switches()
+    names = {t[0] for t in table}
+    assert len(names) == len(table) and all(t[1] in ("force", "value", "path", "diag") and t[2] for t in table)
+    used = set()
+    for f in glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")):
+        src = open(f).read()
+        assert not re.search(r"(?<![A-Za-z_])getenv\(", src.replace("return getenv(name);", "")), f
+        used |= set(re.findall(r'pmx_env\("(PMX_[A-Z0-9_]+)"\)', src))
+    assert used == names, (used - names, names - used)

@@ -1,0 +1,165 @@
+"""Every dispatch alternative gives the same answer (`-m gpu`).
+
+The library reads a fixed table of environment switches (parasail-rs_amd/csrc/pmx_switches.h, listed by pmx_switches()); each
+"force" switch makes the dispatcher take another implementation of the same function.  This test runs one fixed set of batches --
+every mode x score / statistics / CIGAR text, per-pair and profile arm, DNA and protein, short and long references, a banded batch
+and a score table -- once without switches (checked against the oracle) and once under every force switch, and requires identical
+bytes.  A switch that appears in the table but is unknown here fails the test, so none can be added without coverage.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from util import random_seqs, mutate, DNA, AA
+
+pytestmark = pytest.mark.gpu
+
+# switches whose alternative is only reachable together with another one (the partner is set too)
+PARTNERS = {"PMX_STATS_BY_TRACE_ANY": ["PMX_STATS_BY_TRACE"]}
+VALUES = {"PMX_SW16_VARIANT": ["0", "1", "2"], "PMX_STATS_CHUNK_BYTES": ["3e6"], "PMX_CIGAR_CHUNK_BYTES": ["3e6"]}
+NOT_A_DISPATCH_CHOICE = {"PMX_MATRIX_DIR", "PMX_TIMING"}          # a path (tests/test_abi.py) and a diagnostics print
+
+
+def _suite(pkg, orc):
+    """[(label, callable returning a tuple of numpy arrays / bytes)], plus oracle expectations for the score batches."""
+    rng = np.random.default_rng(9700)
+    dna_p, dna_o = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    b62_p, b62_o = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    n = 2600                                                        # above the 2048-pair thresholds of the batch kernels
+    dq = random_seqs(rng, n, 20, 150); dr = [mutate(rng, q, 0.1, 0.03) if k % 3 else random_seqs(rng, 1, 20, 160)[0] for k, q in enumerate(dq)]
+    pq = random_seqs(rng, n, 20, 120, AA); pr = [mutate(rng, q, 0.3, 0.05, AA) if k % 2 else random_seqs(rng, 1, 20, 140, AA)[0] for k, q in enumerate(pq)]
+    one_q = random_seqs(rng, 1, 90, 90, AA)[0]
+    lq = random_seqs(rng, 200, 100, 200); lr = random_seqs(rng, 200, 1100, 1500)          # references beyond the 1024 staging limit
+    packs = {k: orc.pack(v) for k, v in dict(dq=dq, dr=dr, pq=pq, pr=pr, lq=lq, lr=lr).items()}
+    cases, expect = [], {}
+
+    def builder(mat, o, e, mode, width=16):
+        b = pkg.Aligner.new().matrix(mat).gap_open(o).gap_extend(e).solution_width(width)
+        {"sw": b.local, "nw": b.global_, "sg": b.semi_global}[mode]()
+        return b
+
+    def rec(a):
+        return np.stack([a["score"], a["end_query"], a["end_ref"]], axis=1)
+
+    for mode, om in (("sw", orc.SW), ("nw", orc.NW), ("sg", orc.SG)):
+        for tag, mat, omat, o, e, qk, rk in (("dna", dna_p, dna_o, 5, 2, "dq", "dr"), ("prot", b62_p, b62_o, 11, 1, "pq", "pr"),
+                                          ("longref", dna_p, dna_o, 5, 2, "lq", "lr")):
+            (qb, qo), (rb, ro) = packs[qk], packs[rk]
+            al = builder(mat, o, e, mode).build()
+            cases.append(("%s/%s/score" % (mode, tag), lambda al=al, qb=qb, qo=qo, rb=rb, ro=ro: (rec(al.align_batch_packed(qb, qo, rb, ro)),)))
+            expect["%s/%s/score" % (mode, tag)] = orc.align_batch(om, qb, qo, rb, ro, o, e, omat)
+            if tag != "longref":
+                als = builder(mat, o, e, mode).use_stats().build()
+
+                def stats(als=als, qb=qb, qo=qo, rb=rb, ro=ro):
+                    r, s = als.align_batch_packed(qb, qo, rb, ro)
+                    return rec(r), np.stack([s[f] for f in s.dtype.names], axis=1)
+                cases.append(("%s/%s/stats" % (mode, tag), stats))
+                alt = builder(mat, o, e, mode).use_trace().build()
+
+                def cigar(alt=alt, qb=qb, qo=qo, rb=rb, ro=ro):
+                    r, text, coff = alt.align_batch_cigar_packed(qb, qo, rb, ro)
+                    return rec(r), np.array(text, copy=True), coff
+                cases.append(("%s/%s/cigar" % (mode, tag), cigar))
+        # profile arm: one protein query against the protein references
+        prof = pkg.Profile.new(one_q, False, b62_p)
+        (rb, ro) = packs["pr"]
+        alp = builder(b62_p, 11, 1, mode).profile(prof).build()
+        cases.append(("%s/profile/score" % mode, lambda alp=alp, rb=rb, ro=ro: (rec(alp.align_batch_packed(None, None, rb, ro)),)))
+        qb1 = np.tile(np.frombuffer(one_q, dtype=np.uint8), len(ro) - 1); qo1 = np.arange(len(ro), dtype=np.int64) * len(one_q)
+        expect["%s/profile/score" % mode] = orc.align_batch(om, qb1, qo1, rb, ro, 11, 1, b62_o)
+        alps = builder(b62_p, 11, 1, mode).profile(pkg.Profile.new(one_q, True, b62_p)).build()     # (a statistics profile: profile/mod.rs)
+
+        def pstats(alps=alps, rb=rb, ro=ro):
+            r, s = alps.align_batch_packed(None, None, rb, ro)
+            return rec(r), np.stack([s[f] for f in s.dtype.names], axis=1)
+        cases.append(("%s/profile/stats" % mode, pstats))
+    # equal-length reads (no length sort: the perm-table kernel), small statistics batches, long protein references
+    uq = random_seqs(rng, 4200, 150, 150); ur = random_seqs(rng, 4200, 150, 150)      # (>= 4096 pairs: the kernel's own retry list)
+    (uqb, uqo), (urb, uro) = orc.pack(uq), orc.pack(ur)
+    alu = builder(dna_p, 5, 2, "sw").build()
+    cases.append(("sw/dna150/score", lambda: (rec(alu.align_batch_packed(uqb, uqo, urb, uro)),)))
+    expect["sw/dna150/score"] = orc.align_batch(orc.SW, uqb, uqo, urb, uro, 5, 2, dna_o)
+    for tag, mat, o, e, qs_, rs_ in (("dna", dna_p, 5, 2, dq[:300], dr[:300]),
+                                     ("protlong", b62_p, 11, 1, pq[:300], random_seqs(rng, 300, 1100, 1300, AA))):
+        (sqb, sqo), (srb, sro) = orc.pack(qs_), orc.pack(rs_)
+        alss = builder(mat, o, e, "nw").use_stats().build()
+
+        def small_stats(alss=alss, sqb=sqb, sqo=sqo, srb=srb, sro=sro):
+            r, s = alss.align_batch_packed(sqb, sqo, srb, sro)
+            return rec(r), np.stack([s[f] for f in s.dtype.names], axis=1)
+        cases.append(("nw/%s/stats300" % tag, small_stats))
+    # width 8 (saturation rule), banded batch, one score table
+    al8 = builder(dna_p, 5, 2, "sw", 8).build()
+    (qb, qo), (rb, ro) = packs["dq"], packs["dr"]
+    cases.append(("sw/dna/width8", lambda: (rec(al8.align_batch_packed(qb, qo, rb, ro)),)))
+    alb = builder(dna_p, 5, 2, "nw").build()
+    cases.append(("nw/dna/banded", lambda: (rec(alb.align_batch_banded(dq[:400], dr[:400], 12)),)))
+    alt = builder(dna_p, 5, 2, "sg").use_table().build()
+
+    def table():
+        res = alt.align(dq[1], dr[1])
+        return (np.array(res.get_score_table().as_slice(), copy=True),)
+    cases.append(("sg/dna/table", table))
+    return cases, expect
+
+
+def _run(cases, pkg=None, kernels=None):
+    out = {}
+    for label, fn in cases:
+        out[label] = fn()
+        if kernels is not None:
+            kernels[label] = pkg.lib.pmx_last_kernel().decode()
+    return out
+
+
+def _same(a, b):
+    return len(a) == len(b) and all(x.shape == y.shape and (x == y).all() for x, y in zip(a, b))
+
+
+def test_every_switch_is_result_neutral(pkg, orc, monkeypatch):
+    table = pkg.switches()
+    names = [t[0] for t in table]
+    assert len(set(names)) == len(names)
+    for name, kind, what in table:
+        assert name.startswith("PMX_") and kind in ("force", "value", "path", "diag") and what, (name, kind)
+        monkeypatch.delenv(name, raising=False)
+    cases, expect = _suite(pkg, orc)
+    base_kernels = {}
+    base = _run(cases, pkg, base_kernels)
+    for label, k in base_kernels.items():
+        print("%-24s %s" % (label, k))
+    assert "permtable" in base_kernels["sw/dna150/score"] and "shared profile" in base_kernels["nw/profile/stats"]
+    for label, want in expect.items():                                # the unswitched run against the oracle
+        got = base[label][0]
+        bad = np.nonzero((got != want[:, :3]).any(axis=1))[0]
+        assert len(bad) == 0, (label, bad[:5], got[bad[:3]], want[bad[:3]])
+    runs, inert = [], []
+    for name, kind, what in table:
+        if name in NOT_A_DISPATCH_CHOICE:
+            continue
+        if kind == "force":
+            runs.append({name: "1", **{p: "1" for p in PARTNERS.get(name, [])}})
+        else:
+            assert name in VALUES, "switch %s (%s) has no test values" % (name, kind)
+            runs += [{name: v} for v in VALUES[name]]
+    for env in runs:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        kernels = {}
+        try:
+            got = _run(cases, pkg, kernels)
+        finally:
+            for k in env:
+                monkeypatch.delenv(k, raising=False)
+        for label in base:
+            assert _same(base[label], got[label]), (env, label)
+        changed = [label for label in base if kernels[label] != base_kernels[label]]
+        print("%-40s rerouted %2d of %d cases%s" % (" ".join("%s=%s" % kv for kv in env.items()), len(changed), len(base),
+                                                   (": " + changed[0] + " -> " + kernels[changed[0]]) if changed else ""))
+        inert.append(env) if not changed else None
+    # a switch that reroutes nothing here would be tested in name only (chunk sizes and variant caps change no kernel name)
+    same_name = set(VALUES) | {"PMX_CIGAR_NO_OVERLAP", "PMX_TRACE_NO_BFI", "PMX_TRACE_FETCH",      # another instance / schedule of one kernel
+                               "PMX_NO_FAST_TABLE"}                                               # (single calls do not record a name)
+    assert all(any(k in same_name for k in env) for env in inert), inert
