@@ -1217,3 +1217,44 @@ def test_host_entry_pipelined_slices_with_mixed_lengths(pkg, orc):
     torch.cuda.synchronize()
     o = out.cpu().numpy()
     assert (o[:, 0] == got["score"]).all() and (o[:, 1] == got["end_query"]).all() and (o[:, 2] == got["end_ref"]).all()
+
+
+@pytest.mark.parametrize("qlen,rlen,n", [(150, 150, 6000), (250, 250, 4200), (480, 700, 4100), (1000, 2000, 4100)])
+def test_sw16_end_position_under_ties(pkg, orc, qlen, rlen, n):
+    """End cells when the best score occurs several times (the first in column-major order must win): references that
+    carry the same query segment twice (equal scores in two columns), queries that carry a segment twice (equal scores
+    in two rows of one column, in different lanes of the pair's group), both at once, and exact duplicates of whole
+    reads -- the cases the kernel's shared score bound and its tie rule decide (pmx_sw16.hip, share_bound).  Every pair
+    against the oracle, batch sizes above the perm-table kernel's threshold, one shape per lane-group width."""
+    rng = np.random.default_rng(31000 + qlen)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs, rs = [], []
+    for k in range(n):
+        seg = random_seqs(rng, 1, 12, 40)[0]
+        kind = k % 5
+        q = bytearray(random_seqs(rng, 1, qlen, qlen)[0]); r = bytearray(random_seqs(rng, 1, rlen, rlen)[0])
+        def put(buf, pos, s):
+            buf[pos:pos + len(s)] = s
+        if kind in (0, 2):                       # the segment twice in the reference
+            a = int(rng.integers(0, rlen // 2 - 40)); b = int(rng.integers(rlen // 2, rlen - 40))
+            put(r, a, seg); put(r, b, seg)
+            put(q, int(rng.integers(0, qlen - 40)), seg)
+        if kind in (1, 2):                       # the segment twice in the query, far apart (different lanes of the group)
+            a = int(rng.integers(0, qlen // 2 - 40)); b = int(rng.integers(qlen // 2, qlen - 40))
+            put(q, a, seg); put(q, b, seg)
+            if kind == 1:
+                put(r, int(rng.integers(0, rlen - 40)), seg)
+        if kind == 3:                            # identical reads (the diagonal), and a shifted copy
+            m = min(qlen, rlen)
+            r[:m] = q[:m]
+        if kind == 4 and k % 10 == 4:            # periodic sequences: ties everywhere
+            unit = random_seqs(rng, 1, 3, 7)[0]
+            q = bytearray((unit * (qlen // len(unit) + 1))[:qlen]); r = bytearray((unit * (rlen // len(unit) + 1))[:rlen])
+        qs.append(bytes(q)); rs.append(bytes(r))
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    al = pkg.Aligner.new().local().matrix(pm).gap_open(5).gap_extend(2).solution_width(16).build()
+    got = al.align_batch_packed(qb, qo, rb, ro)
+    assert "permtable" in pkg.lib.pmx_last_kernel().decode()
+    want = orc.align_batch(orc.SW, qb, qo, rb, ro, 5, 2, om)
+    bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], got[bad[:5]], want[bad[:5]])
