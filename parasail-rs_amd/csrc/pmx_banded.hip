@@ -168,20 +168,259 @@ void pmx_banded_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form (round 2): the same mapping with both sequences of every pair staged in LDS and a lean interior loop.
+//
+// pmx_banded_kernel above decides everything per cell (where the cell lies, which neighbour comes from which lane, whether a
+// boundary value applies, two global loads for its symbols): ~140 VALU instructions per cell.  Almost all cells of a band lie
+// in the interior of the matrix, where none of those decisions is open.  Here
+//   * a pair's step counter starts at an even offset of its band, so the parity p(s) is the same in every lane of the wave
+//     and the loop is unrolled by it: on even steps the cell to the left comes from lane x - 1 and the cell above is the lane's
+//     own previous cell, on odd steps the other way round -- two DPP moves per step, no selects;
+//   * both sequences are staged in LDS already mapped (query: symbol * msize as 16 bits, reference: symbol as a byte), so a
+//     cell's score is two LDS reads at immediate offsets, one add and one read of the matrix;
+//   * the steps are grouped in blocks of eight.  Before the sweep every lane computes the range of blocks in which all its
+//     cells are interior cells (rows 1 .. qlen - 2, columns 1 .. rlen - 2); the wave takes the intersection and runs those
+//     blocks in the lean loop (H, E and F kept pre-subtracted: E = max(E' , H'), ~16 instructions per cell), everything
+//     before and after in the checked step (the logic of the kernel above, reading symbols from LDS);
+//   * cells outside the band are never masked in the lean loop: lanes beyond the band compute on "minus infinity" inputs that
+//     stay far below every real value, only the band's last lane is forced on odd steps (its odd diagonal is outside).
+// Same results as the kernel above, cell for cell (tests/test_gpu_banded.py runs both against the banded oracle).
+template <int LP, bool SW>
+__global__ __launch_bounds__(64)
+void pmx_banded_staged_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff, int q_shared,
+                              const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff, long long n,
+                              const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap, int msize,
+                              int mode, int sg_flags, int open, int ext, int band, const int32_t *__restrict__ diag,
+                              int QC, int RC /* staging capacity per pair: symbols */, pmx_record_t *__restrict__ out)
+{
+    __shared__ int16_t mat[PMX_MAX_FAST_MSIZE * PMX_MAX_FAST_MSIZE];
+    __shared__ unsigned char map[256];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    for (int x = threadIdx.x; x < msize * msize; x += 64) mat[x] = gmat[x];
+    for (int x = threadIdx.x; x < 256; x += 64) map[x] = gmap[x];
+    __syncthreads();
+
+    constexpr int NPW = 64 / LP;
+    const int lane = threadIdx.x, x = lane % LP, grp = lane / LP;
+    const long long pair = (long long)blockIdx.x * NPW + grp;
+    const bool have = pair < n;
+    const long long pp = have ? pair : n - 1;
+    const long long qb = q_shared ? 0 : qoff[pp], rb = roff[pp];
+    const int ql = min(q_shared ? q_shared : (int)(qoff[pp + 1] - qb), QC), rl = min((int)(roff[pp + 1] - rb), RC);
+    const int d0 = diag ? diag[pp] : 0;
+    const bool sg = mode == PMX_MODE_SG;
+    const bool s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
+    const bool col_pen = mode == PMX_MODE_NW || (sg && !(sg_flags & PMX_SG_QB));
+    const bool row_pen = mode == PMX_MODE_NW || (sg && !(sg_flags & PMX_SG_DB));
+    auto rowB = [&](int j) -> int { return SW ? 0 : (row_pen ? -(open + j * ext) : 0); };
+    auto colB = [&](int i) -> int { return SW ? 0 : (col_pen ? -(open + i * ext) : 0); };
+
+    // ---- stage the mapped sequences: pair g of the wave owns qm[g] (16-bit: symbol * msize) and rm[g] (bytes) --------------
+    unsigned short *qm_all = reinterpret_cast<unsigned short *>(dyn);
+    unsigned char *rm_all = dyn + (size_t)NPW * QC * 2;
+#pragma unroll
+    for (int g2 = 0; g2 < NPW; ++g2) {
+        const long long qb2 = __shfl(qb, g2 * LP, 64), rb2 = __shfl(rb, g2 * LP, 64);
+        const int ql2 = __shfl(ql, g2 * LP, 64), rl2 = __shfl(rl, g2 * LP, 64);
+        for (int t = lane; t < ql2; t += 64) qm_all[g2 * QC + t] = (unsigned short)(map[qbuf[qb2 + t]] * msize);
+        for (int t = lane; t < rl2; t += 64) rm_all[g2 * RC + t] = map[rbuf[rb2 + t]];
+    }
+    __syncthreads();
+    const unsigned short *qm = qm_all + grp * QC;
+    const unsigned char *rm = rm_all + grp * RC;
+
+    // ---- the pair's steps: s = s0 + tau with (s0 + band - d0) even, so the parity of tau is the parity of the diagonal -------
+    const int dlo = d0 - band, dhi = d0 + band;
+    int s_first = 0;
+    if (dlo > 0) s_first = dlo; else if (dhi < 0) s_first = -dhi;
+    int s_last = -1;
+    {
+        int i1 = ql - 1, j1 = rl - 1;
+        if (j1 - i1 > dhi) j1 = i1 + dhi; else if (j1 - i1 < dlo) i1 = j1 - dlo;
+        if (i1 >= 0 && j1 >= 0 && have) s_last = i1 + j1;
+    }
+    if (dlo > rl - 1 || dhi < -(ql - 1)) s_last = -1;
+    const int s0 = s_first - ((s_first + band - d0) & 1);
+    int nsteps = s_last - s0 + 1; if (nsteps < 0) nsteps = 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, off, 64));
+    // lane x at local step tau = 2 m + p: row I0 + m, column J0 + m + p
+    const int I0 = ((s0 + band - d0) >> 1) - x, J0 = I0 + 2 * x - band + d0;
+
+    int Hm1 = B_NEG, Em1 = B_NEG, Fm1 = B_NEG, Hm2 = B_NEG;
+    BCand best = {B_NEG, 0, 0}, brow = {B_NEG, 0, 0}, bcol = {B_NEG, 0, 0};
+    int corner = B_NEG;
+
+    auto checked_step = [&](int tau) {
+        const int p = tau & 1, m = tau >> 1;
+        const int s = s0 + tau, u = 2 * x + p, i = I0 + m, j = J0 + m + p;
+        const bool inside = i >= 0 && i < ql && j >= 0 && j < rl;
+        const int sc = inside ? (int)mat[qm[i] + rm[j]] : 0;
+        const bool active = have && s <= s_last && u <= 2 * band && inside;
+        const int belowH = b_from_below<LP>(Hm1), belowE = b_from_below<LP>(Em1);
+        const int aboveH = b_from_above<LP>(Hm1), aboveF = b_from_above<LP>(Fm1);
+        int upH = p ? aboveH : Hm1, upF = p ? aboveF : Fm1;
+        int leftH = p ? Hm1 : belowH, leftE = p ? Em1 : belowE;
+        int dg = Hm2;
+        if (u + 1 > 2 * band || (p && x == LP - 1)) { upH = B_NEG; upF = B_NEG; }
+        if (u == 0) { leftH = B_NEG; leftE = B_NEG; }
+        if (i == 0) { upH = rowB(j); upF = B_NEG; dg = j == 0 ? 0 : rowB(j - 1); }
+        if (j == 0) { leftH = colB(i); leftE = B_NEG; dg = i == 0 ? 0 : colB(i - 1); }
+        int E = max(leftE - ext, leftH - open); if (E < B_NEG) E = B_NEG;
+        int F = max(upF - ext, upH - open); if (F < B_NEG) F = B_NEG;
+        int H = max(dg + sc, max(E, F));
+        if (SW && H < 0) H = 0;
+        if (!active) { H = B_NEG; E = B_NEG; F = B_NEG; }
+        else {
+            const BCand c = {H, i, j};
+            if (SW) { if (b_better_sw(c, best)) best = c; }
+            else {
+                if (i == ql - 1 && j == rl - 1) corner = H;
+                if (i == ql - 1 && s2_end && (H > brow.H || (H == brow.H && j < brow.j))) brow = c;
+                if (j == rl - 1 && s1_end && (H > bcol.H || (H == bcol.H && i < bcol.i))) bcol = c;
+            }
+        }
+        Hm2 = Hm1; Hm1 = H; Em1 = E; Fm1 = F;
+    };
+
+    // ---- the interior blocks (eight steps each) of this lane, then of the wave --------------------------------------------
+    // block B: rows I0 + 4 B .. + 3, columns J0 + 4 B .. + 4, all of them in 1 .. len - 2
+    int Blo = -(1 << 28), Bhi = 1 << 28;
+    if (x <= band) {
+        Blo = max((1 - I0 + 3) >> 2, (1 - J0 + 3) >> 2);
+        Bhi = min((ql - 5 - I0) >> 2, (rl - 6 - J0) >> 2);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { Blo = max(Blo, __shfl_xor(Blo, off, 64)); Bhi = min(Bhi, __shfl_xor(Bhi, off, 64)); }
+    Blo = max(Blo, 0); Bhi = min(Bhi, (nsteps >> 3) - 1);
+    if (band < 1 || Bhi - Blo < 1) { Blo = 0; Bhi = -1; }            // too short for the lean loop to pay
+
+    int tau = 0;
+    for (; tau < (Bhi >= Blo ? 8 * Blo : nsteps); ++tau) checked_step(tau);
+
+    if (Bhi >= Blo) {
+        // Values are kept biased by 2^30 here ("minus infinity" = B_NEG = -2^30 becomes 0), so a DPP move that zero-fills the
+        // lanes without a source delivers "outside the band" by itself: no select at the band's first and last lane.
+        constexpr int BIAS = 1 << 30;
+        const int keep_odd = x >= band ? 0 : -1;                      // the lane's odd diagonal lies outside the band: forced to 0
+        const int floorv = x <= band ? BIAS : 0;                      // (SW) zero floor only inside the band
+        const int first_ok = x == 0 ? 0 : -1, last_ok = x == LP - 1 ? 0 : -1;      // LP == 32: the wave-wide shift crosses the groups
+        int Hr1 = Hm1 + BIAS, Hr2 = Hm2 + BIAS, Ho1 = Hm1 + BIAS - open, Ee1 = Em1 + BIAS - ext, Fe1 = Fm1 + BIAS - ext;
+        int bH = 0, bT = 0;
+        const unsigned short *qp = qm + I0 + 4 * Blo;                 // the block's 4 rows
+        const unsigned char *rp = rm + J0 + 4 * Blo;                  // and 5 columns (the fifth is the next block's first)
+        auto below = [&](int v) -> int {                              // value of lane x - 1, 0 at the band's first lane
+            int r = __builtin_amdgcn_update_dpp(0, v, LP == 16 ? 0x111 /*row_shr:1*/ : 0x138 /*wave_shr:1*/, 0xF, 0xF, true);
+            if (LP == 32) r &= first_ok;
+            return r;
+        };
+        auto above = [&](int v) -> int {                              // value of lane x + 1, 0 at the group's last lane
+            int r = __builtin_amdgcn_update_dpp(0, v, LP == 16 ? 0x101 /*row_shl:1*/ : 0x130 /*wave_shl:1*/, 0xF, 0xF, true);
+            if (LP == 32) r &= last_ok;
+            return r;
+        };
+        for (int B = Blo; B <= Bhi; ++B) {
+            int sc[8];
+            {
+                int mq[4], mr[5];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mq[k] = qp[k];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) mr[k] = rp[k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { sc[2 * k] = mat[mq[k] + mr[k]]; sc[2 * k + 1] = mat[mq[k] + mr[k + 1]]; }
+            }
+            qp += 4; rp += 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                {   // even step: left from lane x - 1, up = own previous cell
+                    const int lHo = below(Ho1), lEe = below(Ee1);
+                    const int E = max(lEe, lHo), F = max(Fe1, Ho1);
+                    int H = max(Hr2 + sc[2 * k], max(E, F));
+                    if (SW) { H = max(H, floorv); if (H > bH) { bH = H; bT = 8 * B + 2 * k; } }
+                    Hr2 = Hr1; Hr1 = H; Ho1 = H - open; Ee1 = E - ext; Fe1 = F - ext;
+                }
+                {   // odd step: up from lane x + 1, left = own previous cell
+                    const int uHo = above(Ho1), uFe = above(Fe1);
+                    int E = max(Ee1, Ho1), F = max(uFe, uHo);
+                    int H = max(Hr2 + sc[2 * k + 1], max(E, F));
+                    if (SW) H = max(H, floorv);
+                    H &= keep_odd; E &= keep_odd; F &= keep_odd;      // (nothing real may leak to the lanes beyond the band)
+                    if (SW) { if (H > bH) { bH = H; bT = 8 * B + 2 * k + 1; } }
+                    Hr2 = Hr1; Hr1 = H; Ho1 = H - open; Ee1 = E - ext; Fe1 = F - ext;
+                }
+            }
+        }
+        // back to the plain domain (anything at or below "minus infinity" is minus infinity)
+        auto plain = [&](int v) -> int { return v <= 0 ? B_NEG : v - BIAS; };
+        Hm1 = plain(Hr1); Hm2 = plain(Hr2); Em1 = plain(Ee1 + ext); Fm1 = plain(Fe1 + ext);
+        if (SW && have && bH - BIAS > best.H) {                       // (interior cells come after every earlier candidate of the lane)
+            best.H = bH - BIAS; best.i = I0 + (bT >> 1); best.j = J0 + (bT >> 1) + (bT & 1);
+        }
+        tau = 8 * (Bhi + 1);
+    }
+    for (; tau < nsteps; ++tau) checked_step(tau);
+
+    // ---- reduction over the group (as in the kernel above) -------------------------------------------------------------------
+#pragma unroll
+    for (int off = LP / 2; off >= 1; off >>= 1) {
+        BCand o;
+        o.H = __shfl_xor(best.H, off, 64); o.i = __shfl_xor(best.i, off, 64); o.j = __shfl_xor(best.j, off, 64);
+        if (b_better_sw(o, best)) best = o;
+        o.H = __shfl_xor(brow.H, off, 64); o.i = __shfl_xor(brow.i, off, 64); o.j = __shfl_xor(brow.j, off, 64);
+        if (o.H > brow.H || (o.H == brow.H && o.j < brow.j)) brow = o;
+        o.H = __shfl_xor(bcol.H, off, 64); o.i = __shfl_xor(bcol.i, off, 64); o.j = __shfl_xor(bcol.j, off, 64);
+        if (o.H > bcol.H || (o.H == bcol.H && o.i < bcol.i)) bcol = o;
+        corner = max(corner, __shfl_xor(corner, off, 64));
+    }
+    if (x == 0 && have) {
+        pmx_record_t rec; rec.flags = 0;
+        if (SW) {
+            if (best.H == B_NEG) { rec.score = B_NEG; rec.end_query = 0; rec.end_ref = 0; }
+            else { rec.score = best.H; rec.end_query = best.i; rec.end_ref = best.j; }
+        } else if (mode == PMX_MODE_NW || (!s1_end && !s2_end)) {
+            rec.score = corner; rec.end_query = ql - 1; rec.end_ref = rl - 1;
+        } else {
+            BCand res = brow;
+            if (s1_end && bcol.H > res.H) res = bcol;
+            rec.score = res.H; rec.end_query = res.i; rec.end_ref = res.j;
+        }
+        out[pair] = rec;
+    }
+}
+
 int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,
                       const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
-                      int max_qlen, int max_rlen, int band, const int32_t *diag, pmx_record_t *out, hipStream_t stream)
+                      int max_qlen, int max_rlen, int band, const int32_t *diag, pmx_record_t *out, hipStream_t stream,
+                      const char **kernel_name)
 {
-    (void)max_qlen; (void)max_rlen;
     if (n <= 0) return 0;
     if (pmx_env("PMX_NO_FAST_BANDED")) return 1;
     if (m.msize > PMX_MAX_FAST_MSIZE || band > 63) return 1;       // wider bands: the general kernel masks instead
+    const int LPs = band <= 15 ? 16 : band <= 31 ? 32 : 64, NPW = 64 / LPs;
+    const int QC = (max_qlen + 3) & ~3, RC = (max_rlen + 3) & ~3;
+    const size_t lds = (size_t)NPW * ((size_t)QC * 2 + RC);
+    // staged form: both sequences of the wave's pairs fit the LDS, and "minus infinity" cannot drift into the range of real values
+    const bool staged = !pmx_env("PMX_BANDED_NO_STAGING") && lds <= 60 * 1024 && open <= 512 && ext <= 512 &&
+                        (long long)max_qlen + max_rlen < (1 << 20);
+    const bool sw = mode == PMX_MODE_SW;
 #define LB(LP) hipLaunchKernelGGL((pmx_banded_kernel<LP>), dim3((unsigned)((n + 64 / LP - 1) / (64 / LP))), dim3(64), 0, stream, \
                                   qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, mode, sg_flags, open, ext, band, diag, out)
-    if (band <= 15) LB(16);
-    else if (band <= 31) LB(32);
-    else LB(64);
+#define LS(LP, SWF) hipLaunchKernelGGL((pmx_banded_staged_kernel<LP, SWF>), dim3((unsigned)((n + 64 / LP - 1) / (64 / LP))), dim3(64), lds, stream, \
+                                  qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, mode, sg_flags, open, ext, band, diag, QC, RC, out)
+    if (staged) {
+        if (band <= 15) { if (sw) LS(16, true); else LS(16, false); }
+        else if (band <= 31) { if (sw) LS(32, true); else LS(32, false); }
+        else { if (sw) LS(64, true); else LS(64, false); }
+    } else {
+        if (band <= 15) LB(16);
+        else if (band <= 31) LB(32);
+        else LB(64);
+    }
 #undef LB
+#undef LS
+    if (kernel_name) *kernel_name = staged ? "pmx_banded_staged_kernel" : "pmx_banded_kernel";
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

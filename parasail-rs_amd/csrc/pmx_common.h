@@ -155,7 +155,7 @@ static inline bool pmx_general_lds_fits(int mat_rows, int msize, int max_rlen)
 // computed.  0 launched, 1 not eligible (the general kernel masks instead), <0 HIP error.
 int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,
                       const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
-                      int max_qlen, int max_rlen, int band, const int32_t *diag, pmx_record_t *out, hipStream_t stream);
+                      int max_qlen, int max_rlen, int band, const int32_t *diag, pmx_record_t *out, hipStream_t stream, const char **kernel_name = nullptr);
 
 // Score tables / last rows and columns, row by row at HBM write speed (pmx_table.hip).  0 launched, 1 not eligible, <0 HIP error.
 int pmx_launch_table(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,

@@ -30,9 +30,14 @@ def test_banded_nw_narrow_bands_match_the_banded_oracle(pkg, orc, k):
         assert (want[:, 0] == full[:, 0]).all()
 
 
+@pytest.mark.parametrize("staged", [True, False])
 @pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("k", [3, 15, 16, 31, 32, 63, 100])
-def test_banded_batch_every_mode_with_band_centres(pkg, orc, mode, k):
+@pytest.mark.parametrize("k", [1, 3, 15, 16, 31, 32, 63, 100])
+def test_banded_batch_every_mode_with_band_centres(pkg, orc, mode, k, staged, monkeypatch):
+    """both forms of the band-only kernel (sequences staged in LDS + lean interior loop; per-cell form) and, for k > 63, the
+    masked general kernel"""
+    if not staged:
+        monkeypatch.setenv("PMX_BANDED_NO_STAGING", "1")
     rng = np.random.default_rng(8200 + 10 * k + mode)
     pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
     n = 300
@@ -51,7 +56,7 @@ def test_banded_batch_every_mode_with_band_centres(pkg, orc, mode, k):
     for dg in (None, diag):
         got = al.align_batch_banded(qs, rs, k, dg)
         kernel = pkg.lib.pmx_last_kernel().decode()
-        assert ("pmx_banded_kernel" in kernel) == (k <= 63), kernel
+        assert kernel == ("pmx_general_kernel/banded" if k > 63 else "pmx_banded_staged_kernel" if staged else "pmx_banded_kernel"), kernel
         want = orc.align_banded_batch(mode, qb, qo, rb, ro, 5, 2, om, k, dg)
         bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
         assert len(bad) == 0, (mode, k, dg is None, bad[:5], got[bad[:3]], want[bad[:3]], [(len(qs[x]), len(rs[x])) for x in bad[:3]])
@@ -85,7 +90,7 @@ def test_cfg5_banded_sw_second_pass(pkg, orc):
     rs = [rbuf[roff[k]:roff[k + 1]].tobytes() for k in range(n)]
     band = 48
     got = al.align_batch_banded([], rs, band, diag)
-    assert "pmx_banded_kernel" in pkg.lib.pmx_last_kernel().decode()
+    assert pkg.lib.pmx_last_kernel().decode() == "pmx_banded_staged_kernel"
     assert (got["score"] <= full["score"]).all()
     assert (got["score"][planted] == full["score"][planted]).all()
     assert (got["end_query"][planted] == full["end_query"][planted]).all() and (got["end_ref"][planted] == full["end_ref"][planted]).all()
