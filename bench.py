@@ -56,6 +56,17 @@ VALU_MODEL = {
 }
 
 
+class _Works:
+    """Several collectives of one exchange step behind one wait()."""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 def valu_ceiling(kernel):
     for key in sorted(VALU_MODEL, key=len, reverse=True):
         if key.split("/")[0] in kernel and all(p in kernel for p in key.split("/")[1:]):
@@ -342,6 +353,16 @@ class Cfg4(Workload):
                                           wl.CFG4["len"], wl.CFG4["len"], self.d_out[k % 2].data_ptr(),
                                           self.d_text[k % 2].data_ptr(), self.cap, self.d_toff[k % 2].data_ptr(), stream.cuda_stream)
 
+    def exchange(self, k, sharding, backend):
+        """N > 1: this step's CIGAR text follows the records to rank 0 (sizes first, then offsets and text padded to the longest
+        shard; parasail-rs_amd/sharding.py:gather_text).  Returns the works still in flight."""
+        text, toff = self.d_text[k % 2], self.d_toff[k % 2]
+        if backend != "nccl":
+            text, toff = text.cpu(), toff.cpu()
+        fin, works = sharding.gather_text(text, toff, self.counts, dst=0, async_op=True)
+        self.last_text_gather = fin
+        return works
+
     def finish(self):
         total = int(self.d_toff[self.last_k % 2][-1].item())
         if total > self.cap:
@@ -565,9 +586,12 @@ def main():
                 done.record(stream)
                 with torch.cuda.stream(comm_stream):
                     comm_stream.wait_event(done)
-                    pending.append(sharding.gather_records(out, w.counts, dst=0, async_op=True))
+                    fin, work = sharding.gather_records(out, w.counts, dst=0, async_op=True)
+                    extra = w.exchange(k, sharding, backend) if hasattr(w, "exchange") else []
             else:
-                pending.append(sharding.gather_records(out.cpu(), w.counts, dst=0, async_op=True))
+                fin, work = sharding.gather_records(out.cpu(), w.counts, dst=0, async_op=True)
+                extra = w.exchange(k, sharding, backend) if hasattr(w, "exchange") else []
+            pending.append((fin, _Works([work] + list(extra))))
 
     def drain():
         while pending:
@@ -619,8 +643,8 @@ def main():
             "value_is": "device-resident batch throughput (inputs already in HBM when the timed region starts, the bench contract's "
                         "definition); SURVEY.md 8(d)'s end-to-end form (H2D + kernels + D2H through the host entry) is `pcie_inclusive`",
             "config": {"workload": w.workload, "pairs_per_gpu": w.n, "kernel": kernel, "inputs": "resident in HBM",
-                       "exchange": "none" if world == 1 else "%s gather of 16-B records to rank 0, overlapped" %
-                                   ("RCCL" if backend == "nccl" else backend)},
+                       "exchange": "none" if world == 1 else "%s gather of 16-B records%s to rank 0, overlapped" %
+                                   ("RCCL" if backend == "nccl" else backend, " and of the CIGAR text" if hasattr(w, "exchange") else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc.get("traffic") if pmc else None,
                          "traffic_source": pmc.get("source") if pmc else None,

@@ -56,6 +56,43 @@ def gather_records(local, counts, dst=0, group=None, async_op=False):
     return finish(), None
 
 
+def gather_text(text, toff, counts, dst=0, group=None, async_op=False):
+    """Gather packed CIGAR text (the device-entry layout: one uint8 buffer + int64 offsets[n_g + 1] per rank) to `dst`.
+
+    Two phases, like gather_strings: every rank learns every rank's byte count (one tiny all_gather + one host read, the
+    only synchronisation), then the offsets and the text travel padded to the longest shard.  Returns (finish, works):
+    finish() on `dst` gives (text of all ranks back to back, offsets[sum(counts) + 1]) in rank order, None elsewhere;
+    with async_op the two gathers are in flight until every work in `works` has been waited for."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_local = counts[rank]
+    total = toff[n_local:n_local + 1].clone()
+    sizes = [torch.empty_like(total) for _ in range(world)]
+    dist.all_gather(sizes, total, group=group)
+    nbytes = [int(x.item()) for x in sizes]
+    mx_b, mx_n = max(max(nbytes), 1), max(counts) + 1
+    body = text[:mx_b] if text.shape[0] >= mx_b else torch.cat([text, text.new_zeros(mx_b - text.shape[0])])
+    offs = toff[:mx_n] if toff.shape[0] >= mx_n else torch.cat([toff, toff.new_zeros(mx_n - toff.shape[0])])
+    body, offs = body.contiguous(), offs.contiguous()
+    body_all = [torch.empty_like(body) for _ in range(world)] if rank == dst else None
+    offs_all = [torch.empty_like(offs) for _ in range(world)] if rank == dst else None
+    works = [dist.gather(offs, offs_all, dst=dst, group=group, async_op=async_op),
+             dist.gather(body, body_all, dst=dst, group=group, async_op=async_op)]
+
+    def finish():
+        if rank != dst:
+            return None
+        parts, offsets, base = [], [offs_all[0].new_zeros(1)], 0
+        for g in range(world):
+            parts.append(body_all[g][: nbytes[g]])
+            offsets.append(offs_all[g][1: counts[g] + 1] + base)
+            base += nbytes[g]
+        return torch.cat(parts), torch.cat(offsets)
+    return finish, ([w for w in works if w is not None] if async_op else [])
+
+
 def gather_strings(local_strings, dst=0, group=None):
     """Gather variable-length byte strings (CIGARs) to `dst` in rank order, two phases:
     lengths first (fixed width), then the concatenated bytes padded to the longest shard.

@@ -70,6 +70,29 @@ def main():
     else:
         assert got is None
     assert sharding.gather_strings([], dst=0) in ([], None)
+    # packed text + offsets (the device entry's layout): ragged shards, text buffers larger than what was written
+    counts = [min(bounds[rk + 1], bounds[rk] + 40) - bounds[rk] + 3 * rk for rk in range(world)]     # known to every rank from the plan
+    mine = [("%d:%s" % (rank, c)).encode() for c in (local + ["1=", "2X", "3="] * world)[: counts[rank]]]
+    body = np.frombuffer(b"".join(mine), dtype=np.uint8)
+    toff = np.zeros(counts[rank] + 1, dtype=np.int64); np.cumsum([len(x) for x in mine], out=toff[1:])
+    text = torch.from_numpy(np.concatenate([body, np.full(100 + rank, 0x55, dtype=np.uint8)]))       # capacity > bytes written
+    for async_op in (False, True):
+        fin, works = sharding.gather_text(text, torch.from_numpy(toff), counts, dst=0, async_op=async_op)
+        for w in works:
+            w.wait()
+        res = fin()
+        if rank == 0:
+            all_text, all_off = res
+            raw = all_text.numpy().tobytes()
+            items = [raw[int(all_off[k]):int(all_off[k + 1])].decode() for k in range(sum(counts))]
+            assert int(all_off[0]) == 0 and int(all_off[-1]) == len(raw)
+            pos = 0
+            for rk in range(world):
+                assert all(x.startswith("%d:" % rk) for x in items[pos:pos + counts[rk]]), rk
+                pos += counts[rk]
+            assert items[: counts[0]] == [x.decode() for x in mine]
+        else:
+            assert res is None
     dist.barrier()
     if rank == 0:
         print("dist ok world=%d" % world)

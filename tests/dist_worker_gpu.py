@@ -72,6 +72,43 @@ def main():
         idx = np.arange(0, 3000, 41)
         want = orc.align_stats_sample(orc.SW, idx, qb, qo, rb, ro, 5, 2, om)
         assert (got[idx, :3].numpy() == want[:, :3]).all()
+    # (c) config 4's shape: records AND packed CIGAR text gathered to rank 0 (sharding.gather_text), 6 000 pairs, uneven split
+    n4 = 6000
+    qbuf, qoff, rbuf, roff = wl.make_cfg4(n4)
+    cfg4 = pkg.pmx_config_t(pkg.MODE_SG, pkg.SG_ALL, 5, 2, 16, pkg.WANT_CIGAR, pm.inner)
+    bounds = [0] + [n4 * (k + 1) // world + (7 if k + 1 < world else 0) for k in range(world)]
+    lo, hi = bounds[rank], bounds[rank + 1]
+
+    def run_cigar(lo, hi):
+        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in
+             (qbuf[qoff[lo]:qoff[hi]], qoff[lo:hi + 1] - qoff[lo], rbuf[roff[lo]:roff[hi]], roff[lo:hi + 1] - roff[lo])]
+        m = hi - lo
+        out = torch.zeros((m, 4), dtype=torch.int32, device=dev)
+        cap = 320 * m
+        text = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        toff = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+        pkg.align_batch_cigar_device(cfg4, m, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 250, 250,
+                                     out.data_ptr(), text.data_ptr(), cap, toff.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        return out.cpu(), text.cpu(), toff.cpu()
+
+    rec, text, toff = run_cigar(lo, hi)
+    counts = [bounds[k + 1] - bounds[k] for k in range(world)]
+    got, _ = sharding.gather_records(rec, counts, dst=0)
+    fin, works = sharding.gather_text(text, toff, counts, dst=0, async_op=True)
+    for w_ in works:
+        w_.wait()
+    if rank == 0:
+        all_text, all_off = fin()
+        wrec, wtext, wtoff = run_cigar(0, n4)
+        assert (got == wrec).all()
+        assert all_off.shape[0] == n4 + 1 and (all_off == wtoff).all()
+        total = int(wtoff[-1])
+        assert all_text.shape[0] == total and (all_text == wtext[:total]).all()
+        raw = all_text.numpy().tobytes()
+        idx = np.arange(0, n4, 97)
+        texts, _ = orc.cigar_sample(orc.SG, idx, qbuf, qoff, rbuf, roff, 5, 2, om)
+        assert all(raw[int(all_off[k]):int(all_off[k + 1])].decode() == texts[t] for t, k in enumerate(idx))
     dist.barrier()
     if rank == 0:
         print("dist gpu ok world=%d" % world)
