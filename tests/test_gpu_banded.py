@@ -1,6 +1,8 @@
 """Banded alignment (`-m gpu`): Aligner::banded_nw (/root/reference/src/aligner/mod.rs:454-489, KAT tests/test_parasail.rs:726-736)
 against the banded oracle on NARROW bands, the batch extension (any mode, per-pair band centre: BASELINE config 5's "banded SW"),
 and inputs beyond every LDS-resident limit (long references in the general kernel, long pairs in the band-only kernel)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -171,3 +173,53 @@ def test_ssw_begin_positions_and_packed_cigar(pkg, orc):
         assert got == packed, (q, r, got, packed)
         nontrivial += len(packed) > 2
     assert nontrivial > 300
+
+
+def _seeds(default):
+    spec = os.environ.get("PMX_FUZZ_SEEDS")
+    if not spec:
+        return default
+    a, c = spec.split(":")
+    return list(range(int(a), int(c)))
+
+
+@pytest.mark.parametrize("seed", _seeds([301, 302]))
+def test_fuzz_banded_batches(pkg, orc, seed):
+    """Random banded batches against the banded oracle: every mode and free-end set, random gap models and bands, band centres on
+    and off the planted copy, lengths from 1 symbol to beyond the interior loop's blocks, DNA and protein (both forms of the
+    band-only kernel take these: staged + lean interior loop, or per cell when the switch forces it)."""
+    rng = np.random.default_rng(seed)
+    mats = [(pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3), DNA),
+            (pkg.Matrix.create(b"ACGT", 5, -4), orc.Matrix.create("ACGT", 5, -4), DNA),
+            (pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt"), AA)]
+    for it in range(10):
+        pm, om, alpha = mats[int(rng.integers(0, len(mats)))]
+        mode = int(rng.integers(0, 3))
+        open_ = int(rng.choice([0, 1, 5, 11, 20])); ext = int(rng.choice([0, 1, 2, 5]))
+        k = int(rng.choice([0, 1, 2, 5, 15, 16, 30, 31, 32, 48, 63]))
+        lo, hi = [(1, 12), (5, 60), (40, 300), (200, 900)][int(rng.integers(0, 4))]
+        n = int(rng.choice([1, 3, 64, 257]))
+        qs = random_seqs(rng, n, lo, hi, alpha)
+        rs, diag = [], np.zeros(n, dtype=np.int32)
+        for t, q in enumerate(qs):
+            body = mutate(rng, q, 0.1, 0.05, alpha) if rng.random() < 0.8 else random_seqs(rng, 1, lo, hi, alpha)[0]
+            pre = random_seqs(rng, 1, 0, 50, alpha)[0] if rng.random() < 0.5 else b""
+            post = random_seqs(rng, 1, 0, 50, alpha)[0] if rng.random() < 0.3 else b""
+            rs.append((pre + body + post) or body or b"A")
+            diag[t] = len(pre) + int(rng.integers(-6, 7))
+        b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext)
+        [b.global_, b.semi_global, b.local][mode]()
+        sg = orc.SG_ALL
+        if mode == 1:
+            sg = int(rng.integers(1, 16))
+            qg = [t for f, t in ((orc.S1_BEG, "prefix"), (orc.S1_END, "suffix")) if sg & f]
+            dg = [t for f, t in ((orc.S2_BEG, "prefix"), (orc.S2_END, "suffix")) if sg & f]
+            b.allow_query_gaps(qg).allow_ref_gaps(dg)
+        al = b.build()
+        qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+        for dg_ in (None, diag):
+            got = al.align_batch_banded(qs, rs, k, dg_)
+            want = orc.align_banded_batch(mode, qb, qo, rb, ro, open_, ext, om, k, dg_, sg_flags=sg)
+            bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
+            assert len(bad) == 0, (seed, it, mode, sg, open_, ext, k, lo, hi, n, dg_ is None, pkg.lib.pmx_last_kernel().decode(),
+                                   bad[:5], got[bad[:3]], want[bad[:3]], [(len(qs[x]), len(rs[x])) for x in bad[:3]])

@@ -4,6 +4,8 @@ the CPU oracle on the same seeded inputs; the reference's own known-answer tests
 through the mirrored `Aligner` API so they read like tests/test_parasail.rs."""
 import threading
 
+import os
+
 import numpy as np
 import pytest
 
@@ -1056,7 +1058,16 @@ def test_banded_matches_full_when_band_is_wide(pkg, orc):
 
 
 # ------------------------------------------------------------------------------- fuzz ----
-@pytest.mark.parametrize("seed", [101, 102, 103])
+def _seeds(default):
+    """PMX_FUZZ_SEEDS=a:b widens a fuzz test's seed list for soak runs (the committed default keeps the suite short)."""
+    spec = os.environ.get("PMX_FUZZ_SEEDS")
+    if not spec:
+        return default
+    a, b = spec.split(":")
+    return list(range(int(a), int(b)))
+
+
+@pytest.mark.parametrize("seed", _seeds([101, 102, 103]))
 def test_fuzz_fast_kernel_windows(pkg, orc, seed):
     """Randomised batches aimed at the edges of the fast kernels' exact windows: custom 4-letter matrices whose
     score + open touches 0 and 255, gap models with ext = 0 / ext = open, long references (large column skew),
@@ -1258,3 +1269,44 @@ def test_sw16_end_position_under_ties(pkg, orc, qlen, rlen, n):
     want = orc.align_batch(orc.SW, qb, qo, rb, ro, 5, 2, om)
     bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
     assert len(bad) == 0, (len(bad), bad[:5], got[bad[:5]], want[bad[:5]])
+
+
+@pytest.mark.parametrize("seed", _seeds([201, 202]))
+def test_fuzz_local_end_cells_any_scoring(pkg, orc, seed):
+    """The local kernels' end-cell bookkeeping (strip saves under a wave-uniform branch, the shared score bound, the tie rule)
+    under random scoring -- match / mismatch / gap models including ext = 0 and ext = open -- on batches built to tie: repeated
+    segments in query and reference, duplicates, periodic reads; uniform lengths above the perm-table threshold and ragged
+    lengths (sorted order, LDS profiles); every pair against the oracle."""
+    rng = np.random.default_rng(seed)
+    for it in range(6):
+        match = int(rng.choice([1, 2, 3, 5, 10]))
+        mism = -int(rng.choice([1, 2, 3, 4, 9]))
+        open_ = int(rng.choice([1, 2, 5, 7, 12]))
+        ext = int(rng.choice([0, 1, 2, open_]))
+        ext = min(ext, open_)
+        pm, om = pkg.Matrix.create(b"ACGT", match, mism), orc.Matrix.create("ACGT", match, mism)
+        uniform = it % 2 == 0
+        L = int(rng.choice([64, 100, 150, 200, 260]))
+        n = 4300 if uniform else 2500
+        qs, rs = [], []
+        for k in range(n):
+            ql = L if uniform else int(rng.integers(30, L + 1)); rl = L if uniform else int(rng.integers(30, L + 40))
+            q = bytearray(random_seqs(rng, 1, ql, ql)[0]); r = bytearray(random_seqs(rng, 1, rl, rl)[0])
+            seg = random_seqs(rng, 1, 8, 24)[0][: min(ql, rl) // 3]
+            kind = int(rng.integers(0, 6))
+            def put(buf, s_):
+                pos = int(rng.integers(0, len(buf) - len(s_) + 1)); buf[pos:pos + len(s_)] = s_
+            if kind == 0: put(q, seg); put(r, seg); put(r, seg)
+            elif kind == 1: put(q, seg); put(q, seg); put(r, seg)
+            elif kind == 2: put(q, seg); put(q, seg); put(r, seg); put(r, seg)
+            elif kind == 3: m_ = min(ql, rl); r[:m_] = q[:m_]
+            elif kind == 4:
+                unit = random_seqs(rng, 1, 2, 6)[0]
+                q = bytearray((unit * (ql // len(unit) + 1))[:ql]); r = bytearray((unit * (rl // len(unit) + 1))[:rl])
+            qs.append(bytes(q)); rs.append(bytes(r))
+        qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+        al = pkg.Aligner.new().local().matrix(pm).gap_open(open_).gap_extend(ext).solution_width(16).build()
+        got = al.align_batch_packed(qb, qo, rb, ro)
+        want = orc.align_batch(orc.SW, qb, qo, rb, ro, open_, ext, om)
+        bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
+        assert len(bad) == 0, (seed, it, match, mism, open_, ext, uniform, L, pkg.lib.pmx_last_kernel().decode(), bad[:5], got[bad[:5]], want[bad[:5]])
