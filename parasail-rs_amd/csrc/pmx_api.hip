@@ -1347,7 +1347,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
                                                       nullptr, nullptr, nullptr, nullptr, st, d_stats_out + c0);
                     if (rc) { set_err("stats-by-traceback launch failed (%d)", rc); return rc < 0 ? rc : -1; }
                 }
-                g_last_kernel = variant >= 20 ? "pmx_sw16_kernel/packed trace + pmx_walk16_kernel/stats" : "pmx_nwsg16v_kernel/packed trace + pmx_walk16_kernel/stats";
+                g_last_kernel = variant >= 20 ? "pmx_sw16_kernel/packed trace + pmx_walkp_kernel/stats" : "pmx_nwsg16v_kernel/packed trace + pmx_walkp_kernel/stats";
                 return 0;
             }
         }

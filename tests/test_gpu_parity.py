@@ -905,7 +905,7 @@ def test_stats_by_traceback_protein_short_references(pkg, orc):
         _stats_case(pkg, orc, mode, sg, qs, rs, 11, 1, pm, om)
         k = pkg.lib.pmx_last_kernel().decode()
         # no free end: the packed statistics kernel with matrix lookup; otherwise counts along the packed traceback
-        assert k.endswith("pmx_walk16_kernel/stats") if route == "trace" else k.startswith("pmx_stats16p_kernel") and k.endswith("matrix lookup")
+        assert k.endswith("pmx_walkp_kernel/stats") if route == "trace" else k.startswith("pmx_stats16p_kernel") and k.endswith("matrix lookup")
 
 
 def test_stats16p_matrix_lookup_long_references(pkg, orc):
