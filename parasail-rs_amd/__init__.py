@@ -823,13 +823,17 @@ class Aligner:
         raw = text.tobytes()
         return out, [raw[coff[k]:coff[k + 1]].decode() for k in range(len(roff) - 1)]
 
-    def align_batch_cigar_packed(self, qbuf, qoff, rbuf, roff):
-        """Packed in, packed out: (records, CIGAR text as one uint8 array, int64 offsets[n+1])."""
+    def align_batch_cigar_packed(self, qbuf, qoff, rbuf, roff, out=None, coff=None):
+        """Packed in, packed out: (records, CIGAR text as one uint8 array, int64 offsets[n+1]).  `out` / `coff`: arrays to fill
+        (a caller that aligns batch after batch reuses them; the text block is recycled by the library once its array is gone)."""
         n = len(roff) - 1
         cfg = self._config()
         cfg.want &= ~WANT_STATS
-        out = np.zeros(n, dtype=RECORD_DTYPE)
-        coff = np.zeros(n + 1, dtype=np.int64)
+        out = _record_buffer(out, n)
+        if coff is None:
+            coff = np.zeros(n + 1, dtype=np.int64)
+        elif coff.dtype != np.int64 or coff.shape != (n + 1,) or not coff.flags.c_contiguous:
+            raise BatchError("coff must be a contiguous int64 array of %d offsets" % (n + 1))
         cbuf = C.c_void_p()
         rc = lib.pmx_align_batch_cigar(C.byref(cfg), n, qbuf.ctypes.data, qoff.ctypes.data, rbuf.ctypes.data,
                                        roff.ctypes.data, out.ctypes.data, C.byref(cbuf), coff.ctypes.data)

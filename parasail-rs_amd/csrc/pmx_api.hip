@@ -1840,10 +1840,47 @@ extern "C" int pmx_align_batch_cigar_device(const pmx_config_t *cfg, int64_t n,
 }
 
 // The caller-owned CIGAR text: a malloc block that grows chunk by chunk; device text is copied straight into it.
+// Large text blocks go back to a small pool when the caller releases them with pmx_free(), and the next batch call starts from
+// one: a caller that aligns batch after batch writes into memory that is already paged in (first-touch faults of a fresh
+// 100 MB block cost milliseconds), and the block usually has the right size at once.  At most two blocks, at most 1 GB.
+struct TextPool {
+    std::mutex mx;
+    std::unordered_map<void *, size_t> live;      // blocks handed to callers (capacity)
+    std::vector<std::pair<char *, size_t>> idle;  // blocks given back
+    static constexpr size_t MIN_BLOCK = 1 << 20, MAX_IDLE_BYTES = (size_t)1 << 30;
+    char *take(size_t *cap)
+    {
+        std::lock_guard<std::mutex> lk(mx);
+        if (idle.empty()) return nullptr;
+        size_t best = 0;
+        for (size_t k = 1; k < idle.size(); ++k) if (idle[k].second > idle[best].second) best = k;
+        char *p = idle[best].first; *cap = idle[best].second;
+        idle.erase(idle.begin() + (long)best);
+        return p;
+    }
+    void handed_out(void *p, size_t cap) { if (cap >= MIN_BLOCK) { std::lock_guard<std::mutex> lk(mx); live[p] = cap; } }
+    bool give_back(void *p)                        // true: the pool keeps it
+    {
+        std::lock_guard<std::mutex> lk(mx);
+        auto it = live.find(p);
+        if (it == live.end()) return false;
+        const size_t cap = it->second;
+        live.erase(it);
+        size_t held = 0;
+        for (auto &b : idle) held += b.second;
+        if (idle.size() >= 2 || held + cap > MAX_IDLE_BYTES) return false;
+        idle.emplace_back((char *)p, cap);
+        return true;
+    }
+};
+static TextPool g_text_pool;
+
+// The caller-owned CIGAR text: a malloc block that grows chunk by chunk; device text is copied straight into it.
 struct TextBuf {
     char *p = nullptr; size_t len = 0, cap = 0;
     char *grow(size_t extra)       // room for `extra` more bytes (+ terminator); returns the write position or nullptr
     {
+        if (!p && extra + 1 >= TextPool::MIN_BLOCK / 2) p = g_text_pool.take(&cap);
         if (len + extra + 1 > cap) {
             size_t ncap = cap ? cap * 2 : 4096;
             while (ncap < len + extra + 1) ncap *= 2;
@@ -2079,7 +2116,7 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
         if (rc == 0) {
             if (!text.grow(0)) { set_err("out of memory"); return -1; }
             text.p[text.len] = 0;
-            *cigar_buf = text.p;
+            *cigar_buf = text.p; g_text_pool.handed_out(text.p, text.cap);
             return 0;
         }
     }
@@ -2115,7 +2152,7 @@ extern "C" int pmx_align_batch_cigar(const pmx_config_t *cfg, int64_t n,
     }
     if (!text.grow(0)) { set_err("out of memory"); return -1; }
     text.p[text.len] = 0;
-    *cigar_buf = text.p;
+    *cigar_buf = text.p; g_text_pool.handed_out(text.p, text.cap);
     return 0;
 }
 
@@ -2251,7 +2288,7 @@ extern "C" int pmx_align_profile_batch_multi(const pmx_config_t *cfg, const para
     return multi_run(cfg, profile, n, nullptr, nullptr, rbuf, roff, devices, ndev, out, stats_out);
 }
 
-extern "C" void pmx_free(void *p) { free(p); }
+extern "C" void pmx_free(void *p) { if (p && !g_text_pool.give_back(p)) free(p); }
 
 // Page-locks a caller-owned host buffer (hipHostRegister) so that the host-buffer batch entries copy it by DMA at full PCIe rate
 // instead of through the driver's pageable staging (measured: 39 -> ~55 GB/s); one-time cost, undone by pmx_host_unregister.
