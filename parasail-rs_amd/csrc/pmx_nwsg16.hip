@@ -1514,6 +1514,15 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
             TRYV(8, 19, "pmx_nwsg16v_kernel<8,19>")
             TRYV(8, 20, "pmx_nwsg16v_kernel<8,20>")
         }
+        // one pair or a handful (Aligner::align()): latency = steps x rows per lane of one wave; all 64 lanes on the pair
+        // (pmx_sw16.hip has the same ladder)
+#define TRYLAT(RR)                                                              \
+        if (!longref && b.n <= 64 && q <= 64 * (RR) - 1) {                      \
+            const int rc = launch_nwsgv<64, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
+            if (rc <= 0) { if (kernel_name) *kernel_name = "pmx_nwsg16v_kernel<64," #RR ">"; return rc; } \
+        }
+        TRYLAT(2) TRYLAT(3) TRYLAT(4) TRYLAT(8)
+#undef TRYLAT
         TRYV(16, 10, "pmx_nwsg16v_kernel<16,10>")
         TRYV(16, 16, "pmx_nwsg16v_kernel<16,16>")
         TRYV(32, 10, "pmx_nwsg16v_kernel<32,10>")

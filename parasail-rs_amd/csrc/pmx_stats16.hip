@@ -374,6 +374,10 @@ int pmx_launch_stats16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
                       : launch_stats<GG, RR, 1, false>(b, m, mode, sg_flags, open, ext, d_out, d_stats, stream)); \
         if (rc <= 0) { if (kernel_name) *kernel_name = NAME; return rc; }       \
     }
+    if (b.n <= 64 && W == 1) {          // one pair or a handful (Aligner::align()): all 64 lanes on the pair, few rows per lane
+        TRYS(64, 3, "pmx_stats16_kernel<64,3>")
+        TRYS(64, 5, "pmx_stats16_kernel<64,5>")
+    }
     TRYS(16, 10, "pmx_stats16_kernel<16,10>")
     TRYS(32, 8, "pmx_stats16_kernel<32,8>")
     TRYS(64, 5, "pmx_stats16_kernel<64,5>")

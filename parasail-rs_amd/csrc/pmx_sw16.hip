@@ -726,6 +726,16 @@ int pmx_launch_sw16(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext,
     // (a handful of pairs cannot fill the chip: then latency counts, and the 16-lane shape has half the work per step)
     if (b.n > 2048) { TRY8(7) TRY8(10) TRY8(13) TRY8(16) TRY8(19) TRY8(20) }      // 50 / 75 / 100 / 125 / 150 bp reads
 #undef TRY8
+    // One pair or a handful (Aligner::align() calls one at a time): nothing can fill the chip, the call's latency is the length of
+    // ONE wave's dependent chain -- steps x rows per lane.  All 64 lanes on the pair and as few rows per lane as hold the query
+    // (150 x 150: 213 steps of 3 rows instead of 165 steps of 10).
+#define TRYLAT(RR)                                                              \
+    if (u8ok && sk && !longref && b.n <= 64 && q <= 64 * (RR)) {                \
+        const int rc = launch_one<64, RR, 5>(b, m, open, ext, d_out, stream);   \
+        if (rc <= 0) { if (kernel_name) *kernel_name = "pmx_sw16_kernel<64," #RR ">/max3+vop2+u8+skew"; return rc; } \
+    }
+    TRYLAT(2) TRYLAT(3) TRYLAT(4) TRYLAT(8)
+#undef TRYLAT
     TRY(16, 10, "pmx_sw16_kernel<16,10>")
     TRY(16, 16, "pmx_sw16_kernel<16,16>")
     TRY(32, 10, "pmx_sw16_kernel<32,10>")

@@ -11,6 +11,8 @@ rng = np.random.default_rng(3)
 q, r = random_seqs(rng, 2, 150, 150)
 m = pkg.Matrix.create(b"ACGT", 2, -3)
 for name, b in (("sw_striped_16", pkg.Aligner.new().local().matrix(m).gap_open(5).gap_extend(2).solution_width(16)),
+                ("nw_striped_16", pkg.Aligner.new().matrix(m).gap_open(5).gap_extend(2).solution_width(16)),
+                ("sg_striped_sat", pkg.Aligner.new().semi_global().matrix(m).gap_open(5).gap_extend(2)),
                 ("nw_stats_striped_sat", pkg.Aligner.new().matrix(m).gap_open(5).gap_extend(2).use_stats()),
                 ("sg_trace_striped_sat", pkg.Aligner.new().semi_global().matrix(m).gap_open(5).gap_extend(2).use_trace())):
     al = b.build()
