@@ -491,8 +491,19 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
 
 // One device block + one pinned host block per thread for the one-pair entry: a single H2D, the
 // kernel(s), a single D2H.  (The reference's call is a CPU function of ~20 us; no allocation per call.)
-struct SingleWs { void *dev = nullptr; void *pin = nullptr; size_t cap = 0; int device = -1; };
+struct SingleWs { void *dev = nullptr; void *pin = nullptr; size_t cap = 0; int device = -1; void *big = nullptr; size_t bigcap = 0; int bigdev = -1; };
 static thread_local SingleWs g_single;
+// one device block per host thread for the one-pair calls that return tables (carved up per call: a dozen hipMalloc / hipFree
+// per call cost more than the kernel)
+static void single_big_reserve(size_t bytes)
+{
+    int dev = 0; HIP_OR_DIE(hipGetDevice(&dev));
+    if (g_single.bigdev == dev && g_single.bigcap >= bytes) return;
+    if (g_single.big) (void)hipFree(g_single.big);
+    const size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
+    HIP_OR_DIE(hipMalloc(&g_single.big, cap));
+    g_single.bigcap = cap; g_single.bigdev = dev;
+}
 static void single_reserve(size_t bytes)
 {
     int dev = 0; HIP_OR_DIE(hipGetDevice(&dev));
@@ -567,17 +578,37 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
     }
 
     const size_t cells = (size_t)s1Len * s2Len;
-    DevBuf<uint8_t> dq, dr; DevBuf<int64_t> doff; DevBuf<pmx_record_t> drec; DevBuf<pmx_stats_t> dst;
-    DevBuf<int32_t> dbound, dtab[4], drow[4], dcol[4]; DevBuf<int8_t> dtrace;
-    dq.alloc(s1Len); dr.alloc(s2Len); doff.alloc(4); drec.alloc(1); dst.alloc(1);
-    dbound.alloc((size_t)8 * s2Len);
-    DevBuf<uint8_t> drs;                                     // references beyond the LDS: mapped copy in HBM
+    const int ntab = sp.stats ? 4 : 1;
     const bool rs_fits = pmx_general_lds_fits(matrix->length, matrix->size, s2Len);
-    if (!rs_fits) drs.alloc((size_t)s2Len + 32);
+    // one device block, carved up: [q | r | offsets][record, stats][boundary row][mapped reference][tables][rows, columns][trace]
+    struct Ptr { void *p = nullptr; };
+    struct { uint8_t *p; } dq, dr, drs = {nullptr}; struct { int64_t *p; } doff; struct { pmx_record_t *p; } drec; struct { pmx_stats_t *p; } dst;
+    struct { int32_t *p; } dbound, dtab[4] = {{nullptr}, {nullptr}, {nullptr}, {nullptr}}, drow[4] = {{nullptr}, {nullptr}, {nullptr}, {nullptr}},
+                           dcol[4] = {{nullptr}, {nullptr}, {nullptr}, {nullptr}};
+    struct { int8_t *p; } dtrace = {nullptr};
+    const size_t qpad = ((size_t)s1Len + 7) & ~(size_t)7, rpad = ((size_t)s2Len + 7) & ~(size_t)7, in_bytes = qpad + rpad + 4 * sizeof(int64_t);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_in = carve(in_bytes), o_rec = carve(64), o_bound = carve((size_t)8 * s2Len * sizeof(int32_t)),
+                 o_rs = rs_fits ? 0 : carve((size_t)s2Len + 32);
+    size_t o_tab[4] = {0, 0, 0, 0}, o_row[4] = {0, 0, 0, 0}, o_col[4] = {0, 0, 0, 0}, o_trace = 0;
+    if (sp.table) for (int k = 0; k < ntab; ++k) o_tab[k] = carve(cells * sizeof(int32_t));
+    if (sp.rowcol) for (int k = 0; k < ntab; ++k) { o_row[k] = carve((size_t)s2Len * sizeof(int32_t)); o_col[k] = carve((size_t)s1Len * sizeof(int32_t)); }
+    if (sp.trace) o_trace = carve(cells);
+    single_big_reserve(off);
+    single_reserve(in_bytes + 64);
+    unsigned char *D = (unsigned char *)g_single.big, *h = (unsigned char *)g_single.pin;
+    dq.p = D + o_in; dr.p = D + o_in + qpad; doff.p = (int64_t *)(D + o_in + qpad + rpad);
+    drec.p = (pmx_record_t *)(D + o_rec); dst.p = (pmx_stats_t *)(D + o_rec + 16);
+    dbound.p = (int32_t *)(D + o_bound);
+    if (!rs_fits) drs.p = D + o_rs;
+    if (sp.table) for (int k = 0; k < ntab; ++k) dtab[k].p = (int32_t *)(D + o_tab[k]);
+    if (sp.rowcol) for (int k = 0; k < ntab; ++k) { drow[k].p = (int32_t *)(D + o_row[k]); dcol[k].p = (int32_t *)(D + o_col[k]); }
+    if (sp.trace) dtrace.p = (int8_t *)(D + o_trace);
+    memcpy(h, s1, (size_t)s1Len); memcpy(h + qpad, s2, (size_t)s2Len);
     const int64_t offs[4] = {0, s1Len, 0, s2Len};
-    HIP_OR_DIE(hipMemcpy(dq.p, s1, s1Len, hipMemcpyHostToDevice));
-    HIP_OR_DIE(hipMemcpy(dr.p, s2, s2Len, hipMemcpyHostToDevice));
-    HIP_OR_DIE(hipMemcpy(doff.p, offs, sizeof offs, hipMemcpyHostToDevice));
+    memcpy(h + qpad + rpad, offs, sizeof offs);
+    HIP_OR_DIE(hipMemcpyAsync(D + o_in, h, in_bytes, hipMemcpyHostToDevice, nullptr));
 
     PmxGeneralArgs a; memset(&a, 0, sizeof a);
     a.qbuf = dq.p; a.qoff = doff.p; a.rbuf = dr.p; a.roff = doff.p + 2; a.n = 1; a.max_rlen = s2Len;
@@ -588,10 +619,6 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
     a.bound = dbound.p; a.bound_stride = (long long)8 * s2Len;
     if (!rs_fits) { a.rs_scratch = drs.p; a.rs_stride = (long long)s2Len + 32; }
     a.rec = drec.p; a.stats = dst.p;
-    const int ntab = sp.stats ? 4 : 1;
-    if (sp.table) for (int k = 0; k < ntab; ++k) dtab[k].alloc(cells);
-    if (sp.rowcol) for (int k = 0; k < ntab; ++k) { drow[k].alloc(s2Len); dcol[k].alloc(s1Len); }
-    if (sp.trace) dtrace.alloc(cells);
     a.score_table = dtab[0].p; a.matches_table = dtab[1].p; a.similar_table = dtab[2].p; a.length_table = dtab[3].p;
     a.score_row = drow[0].p; a.matches_row = drow[1].p; a.similar_row = drow[2].p; a.length_row = drow[3].p;
     a.score_col = dcol[0].p; a.matches_col = dcol[1].p; a.similar_col = dcol[2].p; a.length_col = dcol[3].p;
@@ -607,8 +634,10 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
     if (rc == 1) rc = pmx_launch_general(a, sp.stats, nullptr);
     if (rc) die("general kernel launch failed (matrix too large for LDS?)", hipSuccess);
     pmx_record_t rec; pmx_stats_t st = {0, 0, 0};
-    HIP_OR_DIE(hipMemcpy(&rec, drec.p, sizeof rec, hipMemcpyDeviceToHost));
-    if (sp.stats) HIP_OR_DIE(hipMemcpy(&st, dst.p, sizeof st, hipMemcpyDeviceToHost));
+    HIP_OR_DIE(hipMemcpyAsync(h + in_bytes, D + o_rec, 32, hipMemcpyDeviceToHost, nullptr));
+    HIP_OR_DIE(hipStreamSynchronize(nullptr));
+    memcpy(&rec, h + in_bytes, sizeof rec);
+    if (sp.stats) memcpy(&st, h + in_bytes + 16, sizeof st);
     res->score = rec.score; res->end_query = rec.end_query; res->end_ref = rec.end_ref;
     if (rec.flags & PMX_FLAG_SATURATED) res->flag |= F_SATURATED;
     res->matches = st.matches; res->similar = st.similar; res->length = st.length;

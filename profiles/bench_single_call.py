@@ -14,7 +14,9 @@ for name, b in (("sw_striped_16", pkg.Aligner.new().local().matrix(m).gap_open(5
                 ("nw_striped_16", pkg.Aligner.new().matrix(m).gap_open(5).gap_extend(2).solution_width(16)),
                 ("sg_striped_sat", pkg.Aligner.new().semi_global().matrix(m).gap_open(5).gap_extend(2)),
                 ("nw_stats_striped_sat", pkg.Aligner.new().matrix(m).gap_open(5).gap_extend(2).use_stats()),
-                ("sg_trace_striped_sat", pkg.Aligner.new().semi_global().matrix(m).gap_open(5).gap_extend(2).use_trace())):
+                ("sg_trace_striped_sat", pkg.Aligner.new().semi_global().matrix(m).gap_open(5).gap_extend(2).use_trace()),
+                ("sg_table_striped_sat", pkg.Aligner.new().semi_global().matrix(m).gap_open(5).gap_extend(2).use_table()),
+                ("sw_rowcol_striped_sat", pkg.Aligner.new().local().matrix(m).gap_open(5).gap_extend(2).use_last_rowcol())):
     al = b.build()
     for _ in range(20): al.align(q, r)
     t0 = time.perf_counter()
