@@ -631,6 +631,12 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
         rc = pmx_launch_table(sp.mode, sp.sg_flags, open, gap, dm.d, 1, dq.p, doff.p, 0, dr.p, doff.p + 2, s1Len, s2Len,
                               nullptr, dtab[0].p, drow[0].p, dcol[0].p, drec.p, nullptr);
     if (rc < 0) die("table kernel launch failed", (hipError_t)(-rc));
+    if (sp.trace && !sp.table && !sp.rowcol && !sp.stats && sp.band < 0 && !pssm && sp.width != 8 && sp.width != 16) {
+        // trace table alone (use_trace + get_cigar / get_traceback_strings): the same row-by-row kernel writes the bytes
+        rc = pmx_launch_table(sp.mode, sp.sg_flags, open, gap, dm.d, 1, dq.p, doff.p, 0, dr.p, doff.p + 2, s1Len, s2Len,
+                              nullptr, nullptr, nullptr, nullptr, drec.p, nullptr, dtrace.p);
+        if (rc < 0) die("table kernel launch failed", (hipError_t)(-rc));
+    }
     if (rc == 1) rc = pmx_launch_general(a, sp.stats, nullptr);
     if (rc) die("general kernel launch failed (matrix too large for LDS?)", hipSuccess);
     pmx_record_t rec; pmx_stats_t st = {0, 0, 0};

@@ -161,7 +161,7 @@ int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMat
 int pmx_launch_table(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,
                      const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
                      int max_qlen, int max_rlen, const int64_t *tab_off, int32_t *table, int32_t *row_out, int32_t *col_out,
-                     pmx_record_t *out, hipStream_t stream);
+                     pmx_record_t *out, hipStream_t stream, int8_t *trace = nullptr);
 
 // On-device traceback walk: trace tables -> run-length ops (BAM-encoded uint32 per run).
 // ops_off[k] = first slot of pair k in `ops` (capacity qlen+rlen each), nops[k] = runs written.

@@ -40,7 +40,13 @@ __device__ __forceinline__ int t_prefix_max(int v)
 
 struct TCand { int H, i, j; };
 
-template <int C>
+// TRACE: the same sweep also writes the reference's 1-byte-per-cell trace table (src/alignment/table.rs:127-142: H choice
+// ZERO 0 / INS 1 / DEL 2 / DIAG 4, E bit DIAG_E 8 / INS_E 16, F bit DIAG_F 32 / DEL_F 64) with the oracle's rules
+// (oracle/pmx_oracle.c: a gap "opens" when H - open > gap - ext strictly; H prefers DIAG, then DEL, then INS; SW: H <= 0 is
+// ZERO).  The E bit of a cell needs the true H and E of its left neighbour: inside a lane they are at hand, for a lane's first
+// column they come from lane - 1 once the row is done.  One pair's trace through this kernel: ~90 us instead of the 264 us of the
+// general kernel's three 64-row bands.
+template <int C, bool TRACE = false>
 __global__ __launch_bounds__(64)
 void pmx_table_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff, int q_shared,
                       const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff, long long n,
@@ -49,7 +55,7 @@ void pmx_table_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
                       const int64_t *__restrict__ tab_off /* cells before pair k's table; nullptr: one pair at 0 */,
                       int32_t *__restrict__ table, int32_t *__restrict__ row_out /* packed like the references */,
                       int32_t *__restrict__ col_out /* packed like the queries */, long long col_stride_shared,
-                      pmx_record_t *__restrict__ out)
+                      pmx_record_t *__restrict__ out, int8_t *__restrict__ trace_out = nullptr /* TRACE: [qlen][rlen], one pair */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char t_lds[];
     int16_t *mat = reinterpret_cast<int16_t *>(t_lds);                 // transposed: mat[r * msize + q]
@@ -91,12 +97,15 @@ void pmx_table_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
         const int dleft = i == 0 ? 0 : colB(i - 1);                    // H(i-1, -1)
         int diag = t_lane_below(Hp[C - 1], dleft);                     // H(i-1, j0-1)
         int Ht[C];
+        int Tt[TRACE ? C : 1], tb[TRACE ? C : 1];                      // TRACE: T per column, trace byte under construction
         int agg = TNEG;                                                // E leaving this lane's columns if nothing came in, + (C-1) ext
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int s = *reinterpret_cast<const int16_t *>(reinterpret_cast<const unsigned char *>(mat) + rbase[c] + qo);
             const int T = diag + s;
-            int F = max(Fv[c] - ext, Hp[c] - open); if (F < TNEG) F = TNEG;
+            const int F_ext = Fv[c] - ext, F_opn = Hp[c] - open;
+            int F = max(F_ext, F_opn); if (F < TNEG) F = TNEG;
+            if (TRACE) { Tt[c] = T; tb[c] = F_opn > F_ext ? PARASAIL_DIAG_F : PARASAIL_DEL_F; }
             Fv[c] = F;
             diag = Hp[c];
             int h = max(T, F);
@@ -114,12 +123,30 @@ void pmx_table_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
         if (ein < TNEG) ein = TNEG;
         int e = ein;
         int rowmax = TNEG, rowj = 0;
+        int e_last = TNEG;                                             // TRACE: E of the lane's last column (for the next lane's E bit)
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int h = max(Ht[c], e);
-            e = max(e - ext, h - open);
+            if (TRACE) {
+                const int T = Tt[c], F = Fv[c];
+                int hb = (T >= e && T >= F) ? PARASAIL_DIAG : (F >= e ? PARASAIL_DEL : PARASAIL_INS);
+                if (sw && h <= 0) hb = PARASAIL_ZERO;
+                tb[c] |= hb;
+                if (c == C - 1) e_last = e;
+            }
+            const int e_ext = e - ext, e_opn = h - open;
+            if (TRACE && c + 1 < C) tb[c + 1] |= e_opn > e_ext ? PARASAIL_DIAG_E : PARASAIL_INS_E;
+            e = max(e_ext, e_opn);
             Hp[c] = h;
             if (sw && h > rowmax && j0 + c < rl) { rowmax = h; rowj = j0 + c; }
+        }
+        if (TRACE) {
+            // E bit of the lane's first column: the left neighbour is lane - 1's last column (or the boundary column: it always opens)
+            const int hl = t_lane_below(Hp[C - 1], hleft), el = t_lane_below(e_last, TNEG);
+            tb[0] |= (hl - open > el - ext) ? PARASAIL_DIAG_E : PARASAIL_INS_E;
+            int8_t *dst = trace_out + (long long)i * rl + j0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) if (j0 + c < rl) dst[c] = (int8_t)tb[c];
         }
         // ---- outputs of the row ----
         if (tab && C == 4) {                                        // one 16-byte store per lane: 1 KB contiguous per wave and row
@@ -208,20 +235,27 @@ void pmx_table_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
 int pmx_launch_table(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,
                      const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
                      int max_qlen, int max_rlen, const int64_t *tab_off, int32_t *table, int32_t *row_out, int32_t *col_out,
-                     pmx_record_t *out, hipStream_t stream)
+                     pmx_record_t *out, hipStream_t stream, int8_t *trace)
 {
     if (n <= 0) return 0;
     if (pmx_env("PMX_NO_FAST_TABLE")) return 1;
     if (open < ext || ext < 0 || m.msize > PMX_MAX_FAST_MSIZE || max_rlen > 64 * 16 || max_qlen > 100000) return 1;
     if (!tab_off && n > 1 && table) return 1;
+    if (trace && n != 1) return 1;                       // the trace table form serves one pair (Aligner::align() with use_trace)
     const size_t lds = (((size_t)m.msize * m.msize * 2 + 15) & ~(size_t)15) + (size_t)max_qlen + 16 + (max_rlen > 256 ? 4096 : 0);
     if (lds > 150 * 1024) return 1;
-#define LT(CC) do { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_table_kernel<CC>)); if (rc) return rc; \
-               hipLaunchKernelGGL((pmx_table_kernel<CC>), dim3((unsigned)n), dim3(64), lds, stream, qbuf, qoff, q_shared, rbuf, roff, n, \
-                                  m.scores, m.mapper, m.msize, mode, sg_flags, open, ext, tab_off, table, row_out, col_out, (long long)max_qlen, out); } while (0)
-    if (max_rlen <= 64 * 4) LT(4);
-    else if (max_rlen <= 64 * 8) LT(8);
-    else LT(16);
+#define LT(CC, TRF) do { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_table_kernel<CC, TRF>)); if (rc) return rc; \
+               hipLaunchKernelGGL((pmx_table_kernel<CC, TRF>), dim3((unsigned)n), dim3(64), lds, stream, qbuf, qoff, q_shared, rbuf, roff, n, \
+                                  m.scores, m.mapper, m.msize, mode, sg_flags, open, ext, tab_off, table, row_out, col_out, (long long)max_qlen, out, trace); } while (0)
+    if (trace) {
+        if (max_rlen <= 64 * 4) LT(4, true);
+        else if (max_rlen <= 64 * 8) LT(8, true);
+        else LT(16, true);
+    } else {
+        if (max_rlen <= 64 * 4) LT(4, false);
+        else if (max_rlen <= 64 * 8) LT(8, false);
+        else LT(16, false);
+    }
 #undef LT
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;

@@ -102,6 +102,13 @@ def _suite(pkg, orc):
         res = alt.align(dq[1], dr[1])
         return (np.array(res.get_score_table().as_slice(), copy=True),)
     cases.append(("sg/dna/table", table))
+    for mode in ("sw", "nw", "sg"):                    # one-pair trace table (table kernel with trace bytes, or the general kernel)
+        alr = builder(b62_p, 11, 1, mode).use_trace().build()
+
+        def trace(alr=alr):
+            res = alr.align(pq[3], pr[3])
+            return (np.array(res.get_trace_table().as_slice(), copy=True), np.frombuffer(res.get_cigar(pq[3], pr[3]).encode(), dtype=np.uint8))
+        cases.append(("%s/prot/trace1" % mode, trace))
     return cases, expect
 
 

@@ -84,3 +84,35 @@ def test_single_pair_table_accessors_use_the_table_kernel(pkg, orc):
         b = pkg.Aligner.new().matrix(pm).gap_open(4).gap_extend(1).use_last_rowcol(); getattr(b, sel)()
         res = b.build().align(q, r)
         assert (np.array(res.get_score_row()) == w.score_row).all() and (np.array(res.get_score_col()) == w.score_col).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_single_pair_trace_table_from_the_table_kernel(pkg, orc, mode):
+    """Aligner::use_trace on one pair (src/aligner/mod.rs:251-267 -> get_trace_table / get_cigar / get_traceback_strings): the
+    row-by-row kernel writes the reference's byte per cell; every byte, the CIGAR and the three strings against the oracle for
+    lengths that exercise all three column widths per lane (references <= 256, <= 512, <= 1024), ragged row ends, one-symbol
+    sequences, gap models with open == extend (every tie in the E / F bits) and with extend = 0, DNA and protein."""
+    rng = np.random.default_rng(9400 + mode)
+    cases = [(b"ACGT", 2, -3, 5, 2, DNA), (b"ACGT", 1, -1, 1, 1, DNA), (b"ACGT", 3, -2, 4, 0, DNA), (None, 0, 0, 11, 1, AA), (None, 0, 0, 3, 3, AA)]
+    shapes = [(1, 1), (1, 40), (33, 1), (5, 300), (150, 150), (70, 257), (64, 256), (300, 513), (200, 1024), (129, 1023)]
+    for alpha, ma, mi, open_, ext, letters in cases:
+        if alpha is None:
+            pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+        else:
+            pm, om = pkg.Matrix.create(alpha, ma, mi), orc.Matrix.create(alpha.decode(), ma, mi)
+        for ql, rl in shapes:
+            q = random_seqs(rng, 1, ql, ql, letters)[0]
+            r = (mutate(rng, q, 0.15, 0.05, letters) + random_seqs(rng, 1, rl, rl, letters)[0])[:rl] if ql > 20 and rng.random() < 0.7 \
+                else random_seqs(rng, 1, rl, rl, letters)[0]
+            b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext).use_trace()
+            [b.global_, b.semi_global, b.local][mode]()
+            res = b.build().align(q, r)
+            w = orc.align(mode, q, r, open_, ext, om, trace=True)
+            ctx = (mode, open_, ext, ql, rl)
+            assert (res.get_score(), res.get_end_query(), res.get_end_ref()) == (w.score, w.end_query, w.end_ref), ctx
+            got = np.asarray(res.get_trace_table().as_slice()).reshape(len(q), len(r))
+            bad = np.argwhere(got != w.trace_table)
+            assert len(bad) == 0, (ctx, bad[:5], [(int(got[i, j]), int(w.trace_table[i, j])) for i, j in bad[:5]])
+            assert res.get_cigar(q, r) == orc.cigar(w), ctx
+            tb = res.get_traceback_strings(q, r)
+            assert (tb.query, tb.comparison, tb.reference) == orc.traceback_strings(w), ctx
