@@ -1606,6 +1606,7 @@ extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_p
     if (check_cfg(cfg)) return -1;
     if (!profile) { set_err("null profile"); return -1; }
     if (n <= 0) return 0;
+    if (!rbuf || !roff || !out) { set_err("null buffer"); return -1; }
     if (profile->matrix != cfg->matrix) { set_err("profile was built with a different matrix"); return -1; }
     if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
     int32_t mr = 0, mnr = 0; bool bad = false;
@@ -1615,20 +1616,60 @@ extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_p
     cfg = &cfg_s;
     const bool stats = (cfg->want & PMX_WANT_STATS) != 0;
     if (stats && !stats_out) { set_err("stats requested without a stats buffer"); return -1; }
-    DevMat dm;
-    if (get_devmat(cfg->matrix, &dm)) return -1;
-    const size_t rbytes = (size_t)roff[n];
-    DevBuf<uint8_t> dr; DevBuf<int64_t> dro; DevBuf<pmx_record_t> drec; DevBuf<pmx_stats_t> dst;
     struct { const uint8_t *p; } dq;
     if (profile_device_query(profile, &dq.p)) return -1;
-    if (dr.try_alloc(rbytes) || dro.try_alloc(n + 1) || drec.try_alloc(n) || (stats && dst.try_alloc(n))) { set_err("out of device memory"); return -2; }
-    HIP_OR_RET(hipMemcpy(dr.p, rbuf, rbytes, hipMemcpyHostToDevice));
-    HIP_OR_RET(hipMemcpy(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
-    const int rc = run_batch_device(cfg, n, dq.p, nullptr, profile->s1Len, dr.p, dro.p, profile->s1Len, mr,
-                                    drec.p, stats ? dst.p : nullptr, nullptr, profile_has_wildcard(profile));
-    if (rc) return rc;
-    HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * n, hipMemcpyDeviceToHost));
-    if (stats) HIP_OR_RET(hipMemcpy(stats_out, dst.p, sizeof(pmx_stats_t) * n, hipMemcpyDeviceToHost));
+    // References go up in slices on a copy stream while the previous slice is aligned (a slice is sorted and aligned on its own:
+    // the offsets are absolute, a slice is a pointer shift) and finished slices travel back; the device staging is kept per host
+    // thread between calls.  cfg 5's eighth (3.4 GB of references) spends 60 ms on the link, all of it behind the kernels.
+    const size_t rbytes = (size_t)roff[n];
+    struct { uint8_t *p; } dr; struct { int64_t *p; } dro; struct { pmx_record_t *p; } drec; struct { pmx_stats_t *p; } dst = {nullptr};
+    if (scratch_reserve(rbytes + 16, (void **)&dr.p, SCR_HR) || scratch_reserve(sizeof(int64_t) * (n + 1), (void **)&dro.p, SCR_HRO) ||
+        scratch_reserve(sizeof(pmx_record_t) * n, (void **)&drec.p, SCR_HREC) ||
+        (stats && scratch_reserve(sizeof(pmx_stats_t) * n, (void **)&dst.p, SCR_HST))) return -1;
+    static thread_local hipStream_t s_copy = nullptr, s_comp = nullptr;
+    static thread_local hipEvent_t s_up[8], s_done[8];
+    static thread_local int s_dev = -1;
+    int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
+    if (s_dev != dev) {
+        if (s_copy) { (void)hipStreamDestroy(s_copy); (void)hipStreamDestroy(s_comp); for (int k = 0; k < 8; ++k) { (void)hipEventDestroy(s_up[k]); (void)hipEventDestroy(s_done[k]); } }
+        HIP_OR_RET(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+        HIP_OR_RET(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
+        for (int k = 0; k < 8; ++k) {
+            HIP_OR_RET(hipEventCreateWithFlags(&s_up[k], hipEventDisableTiming));
+            HIP_OR_RET(hipEventCreateWithFlags(&s_done[k], hipEventDisableTiming));
+        }
+        s_dev = dev;
+    }
+    // (a slice must still fill the chip: at least 32 k references each)
+    const int K = rbytes >= ((size_t)64 << 20) ? (int)std::max<int64_t>(1, std::min<int64_t>(8, n / 32768)) : 1;
+    // slices of about equal bytes (the references may be ragged)
+    int64_t lo[9]; lo[0] = 0; lo[K] = n;
+    for (int sl = 1; sl < K; ++sl) {
+        const int64_t target = (int64_t)(rbytes / K) * sl;
+        lo[sl] = std::lower_bound(roff, roff + n + 1, target) - roff;
+        if (lo[sl] < lo[sl - 1]) lo[sl] = lo[sl - 1];
+        if (lo[sl] > n) lo[sl] = n;
+    }
+    HIP_OR_RET(hipMemcpyAsync(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s_copy));
+    const int wild = profile_has_wildcard(profile);
+    for (int sl = 0; sl < K; ++sl) {
+        const int64_t a = lo[sl], e = lo[sl + 1];
+        if (e <= a) continue;
+        HIP_OR_RET(hipMemcpyAsync(dr.p + roff[a], rbuf + roff[a], (size_t)(roff[e] - roff[a]), hipMemcpyHostToDevice, s_copy));
+        HIP_OR_RET(hipEventRecord(s_up[sl], s_copy));
+        HIP_OR_RET(hipStreamWaitEvent(s_comp, s_up[sl], 0));
+        const int rc = run_batch_device(cfg, e - a, dq.p, nullptr, profile->s1Len, dr.p, dro.p + a, profile->s1Len, mr,
+                                        drec.p + a, stats ? dst.p + a : nullptr, s_comp, wild);
+        if (rc) { (void)hipStreamSynchronize(s_comp); return rc; }
+        HIP_OR_RET(hipEventRecord(s_done[sl], s_comp));
+    }
+    for (int sl = 0; sl < K; ++sl) {
+        const int64_t a = lo[sl], e = lo[sl + 1];
+        if (e <= a) continue;
+        HIP_OR_RET(hipEventSynchronize(s_done[sl]));
+        HIP_OR_RET(hipMemcpy(out + a, drec.p + a, sizeof(pmx_record_t) * (size_t)(e - a), hipMemcpyDeviceToHost));
+        if (stats) HIP_OR_RET(hipMemcpy(stats_out + a, dst.p + a, sizeof(pmx_stats_t) * (size_t)(e - a), hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 
