@@ -137,12 +137,38 @@ void pmx_general_kernel(const PmxGeneralArgs a)
             pb[0] = bound[0]; pb[1] = bound[1];
             if (STATS) { for (int x = 2; x < 8; ++x) pb[x] = bound[x]; }
         }
+        // Banded: only the columns some row of this 64-row band can reach are swept -- rows 64 b .. 64 b + 63 see columns
+        // [64 b + d - w, 64 b + 63 + d + w]; everything left and right of that range is outside the band for every row of the band,
+        // so the sweep may start there with "minus infinity" to its left.  Work per pair: qlen x (2 w + 190) instead of qlen x rlen.
+        int jlo = 0, jhi = rl - 1, pjhi = rl - 1;            // this band's column range; the previous band's last column
+        if (band_w >= 0) {
+            jlo = max(0, bandi * 64 + band_d - band_w);
+            jhi = min(rl - 1, bandi * 64 + 63 + band_d + band_w);
+            pjhi = min(rl - 1, bandi * 64 - 1 + band_d + band_w);
+            if (jlo > 0) {                                    // the column left of the range is outside the band for all 64 rows ...
+                leftH = NEG_INF; leftM = leftS = leftL = 0;
+                diagH = NEG_INF; diagM = diagS = diagL = 0;
+                if (lane == 0 && bandi == 0) {                // ... but row -1 is the boundary row, which keeps its values
+                    diagH = row_pen ? -(open + (jlo - 1) * ext) : 0;
+                    diagL = row_pen ? jlo : 0;
+                }
+                if (lane == 0 && bandi > 0 && jlo - 1 <= pjhi) {   // ... and (64 b - 1, jlo - 1) may lie inside the band: lane 0's first diagonal source
+                    diagH = bound[8LL * (jlo - 1) + 0];
+                    if (STATS) { diagM = bound[8LL * (jlo - 1) + 2]; diagS = bound[8LL * (jlo - 1) + 3]; diagL = bound[8LL * (jlo - 1) + 4]; }
+                }
+            }
+            if (lane == 0 && bandi > 0 && jlo > 0) {          // the read-ahead of the previous band's row starts at jlo
+                const bool in = jlo <= pjhi;
+                pb[0] = in ? bound[8LL * jlo + 0] : NEG_INF; pb[1] = in ? bound[8LL * jlo + 1] : NEG_INF;
+                if (STATS) { for (int x = 2; x < 8; ++x) pb[x] = in ? bound[8LL * jlo + x] : 0; }
+            }
+        }
         // two-stage LDS pipeline: symbol of column j+2, score of column j+1
-        int sym_n = rs[max(0, min(rl, 1 - lane))];
-        int s_n = mrow[rs[max(0, min(rl, 0 - lane))]];
+        int sym_n = rs[max(0, min(rl, jlo + 1 - lane))];
+        int s_n = mrow[rs[max(0, min(rl, jlo - lane))]];
 
-        const int steps = rl + 63;
-        for (int t = 0; t < steps; ++t) {
+        const int steps = jhi + 1 + 63;
+        for (int t = jlo; t < steps; ++t) {
             const int j = t - lane;
             const int s = s_n;                       // score for column j
             const int rsym_cur = rs[max(0, min(rl, j))];
@@ -155,8 +181,8 @@ void pmx_general_kernel(const PmxGeneralArgs a)
                 upHM = lane_up(oHM); upHS = lane_up(oHS); upHL = lane_up(oHL);
                 upFM = lane_up(oFM); upFS = lane_up(oFS); upFL = lane_up(oFL);
             }
-            const bool active = row_ok && j >= 0 && j < rl;
-            if (lane == 0 && j < rl) {
+            const bool active = row_ok && j >= jlo && j <= jhi;
+            if (lane == 0 && j <= jhi) {
                 if (bandi == 0) {
                     upH = row_pen ? -(open + j * ext) : 0;
                     upF = NEG_INF;
@@ -167,8 +193,13 @@ void pmx_general_kernel(const PmxGeneralArgs a)
                     upH = pb[0]; upF = pb[1];
                     if (STATS) { upHM = pb[2]; upHS = pb[3]; upHL = pb[4]; upFM = pb[5]; upFS = pb[6]; upFL = pb[7]; }
                     if (j + 1 < rl) {
-                        pb[0] = bound[8LL * (j + 1) + 0]; pb[1] = bound[8LL * (j + 1) + 1];
-                        if (STATS) { for (int x = 2; x < 8; ++x) pb[x] = bound[8LL * (j + 1) + x]; }
+                        if (j + 1 <= pjhi) {
+                            pb[0] = bound[8LL * (j + 1) + 0]; pb[1] = bound[8LL * (j + 1) + 1];
+                            if (STATS) { for (int x = 2; x < 8; ++x) pb[x] = bound[8LL * (j + 1) + x]; }
+                        } else {                              // (banded) the previous band never reached that column: outside the band
+                            pb[0] = NEG_INF; pb[1] = NEG_INF;
+                            if (STATS) { for (int x = 2; x < 8; ++x) pb[x] = 0; }
+                        }
                     }
                 }
             }
