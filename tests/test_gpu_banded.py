@@ -223,3 +223,31 @@ def test_fuzz_banded_batches(pkg, orc, seed):
             bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
             assert len(bad) == 0, (seed, it, mode, sg, open_, ext, k, lo, hi, n, dg_ is None, pkg.lib.pmx_last_kernel().decode(),
                                    bad[:5], got[bad[:3]], want[bad[:3]], [(len(qs[x]), len(rs[x])) for x in bad[:3]])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_wide_bands_sweep_only_reachable_columns(pkg, orc, mode):
+    """k > 63 runs in the general kernel, which sweeps per 64-row band of the query only the columns that band can reach: band
+    centres far right of the main diagonal (the first query rows start at column d - k > 0: the boundary ROW is their diagonal
+    source), far left (the band leaves the matrix before the query ends), bands that miss the corner, queries of several 64-row
+    bands and references several times the query; every pair against the banded oracle."""
+    rng = np.random.default_rng(8700 + mode)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2)
+    [b.global_, b.semi_global, b.local][mode]()
+    al = b.build()
+    for k, qlo, qhi, shift in ((64, 100, 400, 250), (80, 60, 700, 600), (127, 300, 301, 40), (200, 65, 130, 900)):
+        n = 120
+        qs = random_seqs(rng, n, qlo, qhi)
+        rs, diag = [], np.zeros(n, dtype=np.int32)
+        for t, q in enumerate(qs):
+            pre = random_seqs(rng, 1, 0, shift)[0] if t % 3 else b""
+            post = random_seqs(rng, 1, 0, shift)[0] if t % 4 == 0 else b""
+            rs.append(pre + mutate(rng, q, 0.08, 0.04) + post)
+            diag[t] = len(pre) + int(rng.integers(-30, 31)) if t % 7 else -int(rng.integers(0, len(q)))     # (every seventh: left of the main diagonal)
+        qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+        got = al.align_batch_banded(qs, rs, k, diag)
+        assert pkg.lib.pmx_last_kernel().decode() == "pmx_general_kernel/banded"
+        want = orc.align_banded_batch(mode, qb, qo, rb, ro, 5, 2, om, k, diag)
+        bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
+        assert len(bad) == 0, (mode, k, bad[:5], got[bad[:3]], want[bad[:3]], [(len(qs[x]), len(rs[x]), int(diag[x])) for x in bad[:3]])
