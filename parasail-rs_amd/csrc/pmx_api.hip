@@ -615,7 +615,7 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
     a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize;
     a.mat_rows = matrix->length; a.pssm = pssm ? 1 : 0;
     a.mode = sp.mode; a.sg_flags = sp.sg_flags; a.open = open; a.ext = gap; a.band = sp.band;
-    a.bits = sp.width;
+    a.bits = sp.width; a.max_qlen = s1Len;
     a.bound = dbound.p; a.bound_stride = (long long)8 * s2Len;
     if (!rs_fits) { a.rs_scratch = drs.p; a.rs_stride = (long long)s2Len + 32; }
     a.rec = drec.p; a.stats = dst.p;
@@ -1140,7 +1140,7 @@ static int general_batch(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
                          const uint8_t *d_qbuf, const int64_t *d_qoff, int q_shared,
                          const uint8_t *d_rbuf, const int64_t *d_roff, int32_t max_rlen,
                          int band, const int32_t *d_diag, bool want_stats,
-                         pmx_record_t *d_out, pmx_stats_t *d_stats_out, hipStream_t st)
+                         pmx_record_t *d_out, pmx_stats_t *d_stats_out, hipStream_t st, int32_t max_qlen = 0)
 {
     const size_t stride = (size_t)8 * max_rlen;
     const bool fits = pmx_general_lds_fits(dm.d.msize, dm.d.msize, max_rlen);
@@ -1159,7 +1159,7 @@ static int general_batch(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
         a.scores = dm.d.scores; a.mapper = dm.d.mapper; a.msize = dm.d.msize; a.mat_rows = dm.d.msize; a.pssm = 0;
         a.mode = cfg->mode; a.sg_flags = cfg->sg_flags; a.open = cfg->open; a.ext = cfg->extend;
         a.band = band; a.diag = d_diag ? d_diag + c0 : nullptr;
-        a.bits = cfg->width;
+        a.bits = cfg->width; a.max_qlen = max_qlen;
         a.bound = (int32_t *)bound; a.bound_stride = (long long)stride;
         if (!fits) { a.rs_scratch = (uint8_t *)bound + (size_t)chunk * stride * sizeof(int32_t); a.rs_stride = (long long)rs_stride; }
         a.rec = d_out + c0; a.stats = d_stats_out ? d_stats_out + c0 : nullptr;
@@ -1404,7 +1404,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
     }
     if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
     const int rcg = general_batch(cfg, dm, n, d_qbuf, d_qoff, q_shared, d_rbuf, d_roff, max_rlen, -1, nullptr,
-                                  (want & PMX_WANT_STATS) != 0, d_out, d_stats_out, st);
+                                  (want & PMX_WANT_STATS) != 0, d_out, d_stats_out, st, max_qlen);
     if (rcg) return rcg;
     g_last_kernel = "pmx_general_kernel";
     return 0;
@@ -1717,7 +1717,7 @@ static int banded_device(const pmx_config_t *cfg, int64_t n, const uint8_t *d_qb
     if (rcb < 0) { set_err("banded kernel launch failed: %s", hipGetErrorString((hipError_t)(-rcb))); return rcb; }
     if (rcb == 0) { g_last_kernel = kname; return 0; }
     const int rc = general_batch(&c, dm, n, d_qbuf, d_qoff, q_shared, d_rbuf, d_roff, max_rlen, band, d_diag, false, d_out, nullptr,
-                                 (hipStream_t)stream);
+                                 (hipStream_t)stream, max_qlen);
     if (rc == 0) g_last_kernel = "pmx_general_kernel/banded";
     return rc;
 }

@@ -140,6 +140,8 @@ struct PmxGeneralArgs {
     int32_t *score_table, *matches_table, *similar_table, *length_table;
     int8_t *trace_table;
     int trace_lds;            // set by the launcher: stage one band of trace bytes in LDS, flush coalesced
+    int max_qlen;             // longest query of the launch (0: unknown); lets the launcher share one long pair among several waves
+    int mw_sched_off;         // set by the launcher (multi-wave form): LDS offset of the band schedule
     // row/col outputs: row offset = roff[k], col offset = qoff[k] (or 0 for n == 1)
     int32_t *score_row, *matches_row, *similar_row, *length_row;
     int32_t *score_col, *matches_col, *similar_col, *length_col;

@@ -251,3 +251,31 @@ def test_wide_bands_sweep_only_reachable_columns(pkg, orc, mode):
         want = orc.align_banded_batch(mode, qb, qo, rb, ro, 5, 2, om, k, diag)
         bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
         assert len(bad) == 0, (mode, k, bad[:5], got[bad[:3]], want[bad[:3]], [(len(qs[x]), len(rs[x]), int(diag[x])) for x in bad[:3]])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_long_single_pairs_share_the_waves_of_a_workgroup(pkg, orc, mode):
+    """Queries beyond the packed kernels' 2048 rows run in the general kernel; with few pairs in flight the 64-row bands of ONE
+    pair are spread over the waves of a workgroup (a pipeline of bands, a barrier per step).  Score, ends and statistics of long
+    similar and dissimilar pairs -- ragged last band, a query of exactly 16 bands, one just beyond -- against the oracle, and the
+    same pairs inside a batch large enough to take the one-wave-per-pair form."""
+    rng = np.random.default_rng(8800 + mode)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2)
+    [b.global_, b.semi_global, b.local][mode]()
+    al, als = b.build(), b.use_stats().build()
+    qs = [random_seqs(rng, 1, L, L)[0] for L in (2049, 2500, 1024 + 2048, 1025 + 2048, 4000)]
+    rs = [mutate(rng, q, 0.1, 0.03) if k % 2 == 0 else random_seqs(rng, 1, 700, 3000)[0] for k, q in enumerate(qs)]
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    want = orc.align_stats_sample(mode, np.arange(len(qs)), qb, qo, rb, ro, 5, 2, om)
+    got = al.align_batch(qs, rs)
+    assert pkg.lib.pmx_last_kernel().decode() == "pmx_general_kernel"
+    assert (got["score"] == want[:, 0]).all() and (got["end_query"] == want[:, 1]).all() and (got["end_ref"] == want[:, 2]).all()
+    rec, st = als.align_batch(qs, rs)
+    assert (rec["score"] == want[:, 0]).all() and (st["matches"] == want[:, 3]).all() and (st["similar"] == want[:, 4]).all() \
+        and (st["length"] == want[:, 5]).all()
+    one = al.align(qs[0], rs[0])
+    assert (one.get_score(), one.get_end_query(), one.get_end_ref()) == tuple(want[0, :3])
+    many_q, many_r = qs[:2] * 40, rs[:2] * 40                      # 80 pairs: one wave per pair
+    big = al.align_batch(many_q, many_r)
+    assert (big["score"][:2] == want[:2, 0]).all() and (big["score"][::2] == want[0, 0]).all() and (big["end_ref"][1::2] == want[1, 2]).all()

@@ -102,6 +102,17 @@ def _suite(pkg, orc):
         res = alt.align(dq[1], dr[1])
         return (np.array(res.get_score_table().as_slice(), copy=True),)
     cases.append(("sg/dna/table", table))
+    # few long pairs in the general kernel (queries beyond 2048 rows; statistics tables): several waves share a pair
+    lq2 = random_seqs(rng, 3, 2100, 2400); lr2 = [mutate(rng, q, 0.1, 0.03) for q in lq2]
+    for mode in ("sw", "nw", "sg"):
+        all_ = builder(dna_p, 5, 2, mode).build()
+        cases.append(("%s/dna/long3" % mode, lambda all_=all_: (rec(all_.align_batch(lq2, lr2)),)))
+        alst = builder(dna_p, 5, 2, mode).use_stats().use_table().build()
+
+        def stats_table(alst=alst):
+            res = alst.align(dq[5] * 3, dr[5] * 3)
+            return tuple(np.array(getattr(res, "get_%s_table" % k)().as_slice(), copy=True) for k in ("score", "matches", "similar", "length"))
+        cases.append(("%s/dna/statstable1" % mode, stats_table))
     for mode in ("sw", "nw", "sg"):                    # one-pair trace table (table kernel with trace bytes, or the general kernel)
         alr = builder(b62_p, 11, 1, mode).use_trace().build()
 
@@ -168,5 +179,5 @@ def test_every_switch_is_result_neutral(pkg, orc, monkeypatch):
         inert.append(env) if not changed else None
     # a switch that reroutes nothing here would be tested in name only (chunk sizes and variant caps change no kernel name)
     same_name = set(VALUES) | {"PMX_CIGAR_NO_OVERLAP", "PMX_TRACE_NO_BFI", "PMX_TRACE_FETCH",      # another instance / schedule of one kernel
-                               "PMX_NO_FAST_TABLE"}                                               # (single calls do not record a name)
+                               "PMX_NO_FAST_TABLE", "PMX_GENERAL_ONE_WAVE"}                       # (single calls do not record a name)
     assert all(any(k in same_name for k in env) for env in inert), inert
