@@ -581,6 +581,31 @@ void pmx_general_mw_kernel(const PmxGeneralArgs a)
                 }
             }
     };
+    // Score only, no band, every lane on a real cell away from the last column (steps 63 .. rlen - 2 of a band that is not the
+    // last): none of the checked step's questions is open -- 25 instructions instead of ~100 (20 kbp x 20 kbp 358 -> 218 ms).
+    // (Measured and dropped: fetching the row above 64 columns at a time one block ahead, 218 -> 267 ms; a barrier only every 16th
+    // step, 218 -> 207 ms but slower banded batches: sixteen waves on one CU are bound by its four SIMDs, not by the barrier.)
+    const bool lean_kind = !STATS && !OUT && band_w < 0 && a.bits != 8 && a.bits != 16;
+    auto do_step_lean = [&](int t) __attribute__((always_inline)) {
+        const int j = t - lane;
+        const int s = s_n;
+        s_n = mrow[sym_n];
+        sym_n = rs[j + 2];
+        int upH = lane_up(oH), upF = lane_up(oF);
+        if (lane == 0) {
+            if (bandi == 0) { upH = row_pen ? -(open + j * ext) : 0; upF = NEG_INF; }
+            else { upH = pb0; upF = pb1; pb0 = bound[8LL * (j + 1) + 0]; pb1 = bound[8LL * (j + 1) + 1]; }
+        }
+        const int F = max(upH - open, upF - ext);
+        E = max(leftH - open, E - ext);
+        int H = max(diagH + s, max(E, F));
+        if (mode == PMX_MODE_SW) {
+            H = max(H, 0);
+            if (H > best_sw.H) { best_sw.H = H; best_sw.i = i; best_sw.j = j; }     // (j ascends in a lane: the first maximum is kept)
+        }
+        diagH = upH; leftH = H; oH = H; oF = F;
+        if (lane == 63) { bound[8LL * j + 0] = H; bound[8LL * j + 1] = F; }
+    };
     // start step of every band: 66 steps (+ the shift of its column range) behind the band above, and not before the wave
     // that owns it has finished its previous band
     int *sched = reinterpret_cast<int *>(lds + a.mw_sched_off);        // [nbands] start steps, then the end step
@@ -603,7 +628,8 @@ void pmx_general_mw_kernel(const PmxGeneralArgs a)
     for (int gs = 0; gs < end; ++gs) {
         if (gs == start) { band_init(cb); t = jlo; t_end = jhi + 1 + 63; }
         if (gs >= start) {
-            do_step(t);
+            if (lean_kind && bandi + 1 < nbands && t >= 63 && t <= rl - 2) do_step_lean(t);
+            else do_step(t);
             if (++t == t_end) { cb += W; start = cb < nbands ? sched[cb] : 0x7fffffff; }
         }
         __syncthreads();                                   // (stores of this step are visible to the whole workgroup after it)
