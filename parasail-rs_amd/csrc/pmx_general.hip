@@ -22,6 +22,9 @@
 #include "pmx_switches.h"
 
 #define NEG_INF (INT32_MIN / 2)
+#ifndef PMX_MW_MAX_PAIRS
+#define PMX_MW_MAX_PAIRS 2048   // up to this many pairs per launch, a pair gets a workgroup of waves instead of one wave (see pmx_general_mw_kernel)
+#endif
 
 #define T_INS 1
 #define T_DEL 2
@@ -169,7 +172,30 @@ void pmx_general_kernel(const PmxGeneralArgs a)
         int s_n = mrow[rs[max(0, min(rl, jlo - lane))]];
 
         const int steps = jhi + 1 + 63;
+        // score only, no band, every lane on a real cell away from the last column: the 25-instruction step (see do_step_lean below)
+        const bool lean_band = !STATS && !OUT && band_w < 0 && a.bits != 8 && a.bits != 16 && bandi + 1 < nbands;
         for (int t = jlo; t < steps; ++t) {
+            if (lean_band && t >= 63 && t <= rl - 2) {
+                const int j = t - lane;
+                const int s = s_n;
+                s_n = mrow[sym_n];
+                sym_n = rs[j + 2];
+                int upH = lane_up(oH), upF = lane_up(oF);
+                if (lane == 0) {
+                    if (bandi == 0) { upH = row_pen ? -(open + j * ext) : 0; upF = NEG_INF; }
+                    else { upH = pb[0]; upF = pb[1]; pb[0] = bound[8LL * (j + 1) + 0]; pb[1] = bound[8LL * (j + 1) + 1]; }
+                }
+                const int F = max(upH - open, upF - ext);
+                E = max(leftH - open, E - ext);
+                int H = max(diagH + s, max(E, F));
+                if (mode == PMX_MODE_SW) {
+                    H = max(H, 0);
+                    if (H > best_sw.H) { best_sw.H = H; best_sw.i = i; best_sw.j = j; }
+                }
+                diagH = upH; leftH = H; oH = H; oF = F;
+                if (lane == 63) { bound[8LL * j + 0] = H; bound[8LL * j + 1] = F; }
+                continue;
+            }
             const int j = t - lane;
             const int s = s_n;                       // score for column j
             const int rsym_cur = rs[max(0, min(rl, j))];
@@ -709,7 +735,10 @@ int pmx_launch_general(const PmxGeneralArgs &a_in, bool want_stats, hipStream_t 
     // Few long pairs: several waves share a pair (see MW in the kernel).  W = bands of the longest query, at most 16.
     const int nbands_max = (a.max_qlen + 63) / 64;
     int W = 1;
-    if (a.n <= 64 && nbands_max >= 3 && nbands_max <= 8192 && !pmx_env("PMX_GENERAL_ONE_WAVE")) W = nbands_max < 16 ? nbands_max : 16;
+    // (a handful of pairs: always -- nothing else would fill the chip; up to PMX_MW_MAX_PAIRS: when a band's sweep is long against the
+    //  66-step stagger of the pipeline, i.e. unbanded pairs with references of >= 1024 symbols)
+    const bool few = a.n <= 64 || (a.n <= PMX_MW_MAX_PAIRS && a.band < 0 && a.max_rlen >= 1024);
+    if (few && nbands_max >= 3 && nbands_max <= 8192 && !pmx_env("PMX_GENERAL_ONE_WAVE")) W = nbands_max < 16 ? nbands_max : 16;
     if (W > 1) {
         a.mw_sched_off = (int)((lds + 15) & ~(size_t)15);
         lds = (size_t)a.mw_sched_off + (((size_t)(nbands_max + 1) * 4 + 15) & ~(size_t)15) + (size_t)W * (4 * sizeof(int) * 6 + 8) + 64;
