@@ -363,8 +363,9 @@ void pmx_general_kernel(const PmxGeneralArgs a)
 // lane 0 reads from the boundary buffer was written by band b - 1's lane 63 in an earlier step; every step ends with a
 // workgroup barrier (that is the whole synchronisation: no flags, no spinning), the start step of every band is computed up front.
 // A single long pair -- Aligner::align() on two 10 kbp sequences -- no longer crawls through 157 bands on one wave.
-// (The one-wave-per-pair kernel above keeps its own copy of the sweep: written as lambdas shared by both drivers, the compiler
-// left the four end-cell candidates in scratch memory and the batch form lost a third of its speed.)
+// (The one-wave-per-pair kernel above keeps its own copy of the sweep: this kernel run with a single wave is a third slower on
+// batches -- 2000 banded pairs 5.0 vs 7.0 ms -- because every step passes through the schedule test and a barrier.  The band set-up
+// and both steps are written out inside the step loop: as lambdas they left the end-cell candidates in scratch memory.)
 template <bool STATS, bool OUT>
 __global__ __launch_bounds__(1024)
 void pmx_general_mw_kernel(const PmxGeneralArgs a)
@@ -431,207 +432,11 @@ void pmx_general_mw_kernel(const PmxGeneralArgs a)
         lo = 0; hi = rl - 1;
         if (band_w >= 0) { lo = max(0, b * 64 + band_d - band_w); hi = min(rl - 1, b * 64 + 63 + band_d + band_w); }
     };
-    auto band_init = [&](int b) __attribute__((always_inline)) {
-        bandi = b;
-        i = bandi * 64 + lane;
-        row_ok = i < ql;
-        qsym = row_ok ? a.mapper[q[i]] : 0;
-        mrow = mat + (a.pssm ? (row_ok ? i : 0) : qsym) * msize;
-        // left boundary H(i,-1) and the diagonal seed H(i-1,-1)
-        leftH = col_pen ? -(open + i * ext) : 0;
-        leftM = 0; leftS = 0; leftL = col_pen ? i + 1 : 0;
-        diagH = (i == 0) ? 0 : (col_pen ? -(open + (i - 1) * ext) : 0);
-        diagM = 0; diagS = 0; diagL = (i == 0) ? 0 : (col_pen ? i : 0);
-        if (row_ok) { hmin = min(hmin, leftH); }
-        E = NEG_INF; EM = 0; ES = 0; EL = 0;
-        // what this lane hands to the lane below: H(i,j), F(i,j) and stats
-        oH = NEG_INF; oF = NEG_INF; oHM = 0; oHS = 0; oHL = 0; oFM = 0; oFS = 0; oFL = 0;
-
-        tdst = nullptr; ts = nullptr;
-        if (tlds) {
-            tdst = a.trace_table + tab0 + (long long)bandi * 64 * rl;
-            ts = tstage + ((uintptr_t)tdst & 15);          // same alignment mod 16 as the destination
-        }
-        // lane 0 reads the previous band's last row one column ahead of its use
-        pb0 = pb1 = pb2 = pb3 = pb4 = pb5 = pb6 = pb7 = 0;
-        if (lane == 0 && bandi > 0) {
-            pb0 = bound[0]; pb1 = bound[1];
-            if (STATS) { pb2 = bound[2]; pb3 = bound[3]; pb4 = bound[4]; pb5 = bound[5]; pb6 = bound[6]; pb7 = bound[7]; }
-        }
-        // Banded: only the columns some row of this 64-row band can reach are swept -- rows 64 b .. 64 b + 63 see columns
-        // [64 b + d - w, 64 b + 63 + d + w]; everything left and right of that range is outside the band for every row of the band,
-        // so the sweep may start there with "minus infinity" to its left.  Work per pair: qlen x (2 w + 190) instead of qlen x rlen.
-        jlo = 0; jhi = rl - 1; pjhi = rl - 1;                // this band's column range; the previous band's last column
-        if (band_w >= 0) {
-            jlo = max(0, bandi * 64 + band_d - band_w);
-            jhi = min(rl - 1, bandi * 64 + 63 + band_d + band_w);
-            pjhi = min(rl - 1, bandi * 64 - 1 + band_d + band_w);
-            if (jlo > 0) {                                    // the column left of the range is outside the band for all 64 rows ...
-                leftH = NEG_INF; leftM = leftS = leftL = 0;
-                diagH = NEG_INF; diagM = diagS = diagL = 0;
-                if (lane == 0 && bandi == 0) {                // ... but row -1 is the boundary row, which keeps its values
-                    diagH = row_pen ? -(open + (jlo - 1) * ext) : 0;
-                    diagL = row_pen ? jlo : 0;
-                }
-                if (lane == 0 && bandi > 0 && jlo - 1 <= pjhi) {   // ... and (64 b - 1, jlo - 1) may lie inside the band: lane 0's first diagonal source
-                    diagH = bound[8LL * (jlo - 1) + 0];
-                    if (STATS) { diagM = bound[8LL * (jlo - 1) + 2]; diagS = bound[8LL * (jlo - 1) + 3]; diagL = bound[8LL * (jlo - 1) + 4]; }
-                }
-            }
-            if (lane == 0 && bandi > 0 && jlo > 0) {          // the read-ahead of the previous band's row starts at jlo
-                const bool in = jlo <= pjhi;
-                pb0 = in ? bound[8LL * jlo + 0] : NEG_INF; pb1 = in ? bound[8LL * jlo + 1] : NEG_INF;
-                if (STATS) { pb2 = in ? bound[8LL * jlo + 2] : 0; pb3 = in ? bound[8LL * jlo + 3] : 0; pb4 = in ? bound[8LL * jlo + 4] : 0;
-                             pb5 = in ? bound[8LL * jlo + 5] : 0; pb6 = in ? bound[8LL * jlo + 6] : 0; pb7 = in ? bound[8LL * jlo + 7] : 0; }
-            }
-        }
-        // two-stage LDS pipeline: symbol of column j+2, score of column j+1
-        sym_n = rs[max(0, min(rl, jlo + 1 - lane))];
-        s_n = mrow[rs[max(0, min(rl, jlo - lane))]];
-
-    };
-    auto do_step = [&](int t) __attribute__((always_inline)) {
-            const int j = t - lane;
-            const int s = s_n;                       // score for column j
-            const int rsym_cur = rs[max(0, min(rl, j))];
-            s_n = mrow[sym_n];
-            sym_n = rs[max(0, min(rl, j + 2))];
-            // --- values of the row above for column j (produced one step ago by lane-1) ---
-            int upH = lane_up(oH), upF = lane_up(oF);
-            int upHM = 0, upHS = 0, upHL = 0, upFM = 0, upFS = 0, upFL = 0;
-            if (STATS) {
-                upHM = lane_up(oHM); upHS = lane_up(oHS); upHL = lane_up(oHL);
-                upFM = lane_up(oFM); upFS = lane_up(oFS); upFL = lane_up(oFL);
-            }
-            const bool active = row_ok && j >= jlo && j <= jhi;
-            if (lane == 0 && j <= jhi) {
-                if (bandi == 0) {
-                    upH = row_pen ? -(open + j * ext) : 0;
-                    upF = NEG_INF;
-                    upHM = upHS = 0; upHL = row_pen ? j + 1 : 0;
-                    upFM = upFS = upFL = 0;
-                    hmin = min(hmin, upH);
-                } else {
-                    upH = pb0; upF = pb1;
-                    if (STATS) { upHM = pb2; upHS = pb3; upHL = pb4; upFM = pb5; upFS = pb6; upFL = pb7; }
-                    if (j + 1 < rl) {
-                        if (j + 1 <= pjhi) {
-                            pb0 = bound[8LL * (j + 1) + 0]; pb1 = bound[8LL * (j + 1) + 1];
-                            if (STATS) { pb2 = bound[8LL * (j + 1) + 2]; pb3 = bound[8LL * (j + 1) + 3]; pb4 = bound[8LL * (j + 1) + 4];
-                                         pb5 = bound[8LL * (j + 1) + 5]; pb6 = bound[8LL * (j + 1) + 6]; pb7 = bound[8LL * (j + 1) + 7]; }
-                        } else {                              // (banded) the previous band never reached that column: outside the band
-                            pb0 = NEG_INF; pb1 = NEG_INF;
-                            if (STATS) { pb2 = pb3 = pb4 = pb5 = pb6 = pb7 = 0; }
-                        }
-                    }
-                }
-            }
-            if (active) {
-                const int rsym = rsym_cur;
-                int T = 0;
-                int F, FM, FS, FL;
-                {
-                    const int F_opn = upH - open, F_ext = upF - ext;
-                    if (F_opn > F_ext) { F = F_opn; FM = upHM; FS = upHS; FL = upHL + 1; T |= T_DIAG_F; }
-                    else { F = F_ext; FM = upFM; FS = upFS; FL = upFL + 1; T |= T_DEL_F; }
-                    if (F < NEG_INF) F = NEG_INF;
-                }
-                {
-                    const int E_opn = leftH - open, E_ext = E - ext;
-                    if (E_opn > E_ext) { E = E_opn; EM = leftM; ES = leftS; EL = leftL + 1; T |= T_DIAG_E; }
-                    else { E = E_ext; EL = EL + 1; T |= T_INS_E; }
-                    if (E < NEG_INF) E = NEG_INF;
-                }
-                const int H_dag = diagH + s;
-                int H, HM, HS, HL;
-                if (H_dag >= E && H_dag >= F) {
-                    H = H_dag; HM = diagM + (qsym == rsym); HS = diagS + (s > 0); HL = diagL + 1; T |= T_DIAG;
-                } else if (F >= E) {
-                    H = F; HM = FM; HS = FS; HL = FL; T |= T_DEL;
-                } else {
-                    H = E; HM = EM; HS = ES; HL = EL; T |= T_INS;
-                }
-                if (mode == PMX_MODE_SW && H <= 0) {
-                    H = 0; HM = HS = HL = 0; T &= ~(T_INS | T_DEL | T_DIAG);
-                }
-                if (band_w >= 0 && (j - i - band_d > band_w || j - i - band_d < -band_w)) {
-                    H = NEG_INF; E = NEG_INF; F = NEG_INF; HM = HS = HL = 0;
-                }
-                hmax = max(hmax, H);
-                if (band_w < 0) hmin = min(hmin, H);
-
-                if (OUT) {
-                    const long long c = tab0 + (long long)i * rl + j;
-                    if (a.score_table) a.score_table[c] = H;
-                    if (STATS) {
-                        if (a.matches_table) a.matches_table[c] = HM;
-                        if (a.similar_table) a.similar_table[c] = HS;
-                        if (a.length_table) a.length_table[c] = HL;
-                    }
-                    if (tlds) ts[lane * rl + j] = (unsigned char)T;
-                    else if (a.trace_table) a.trace_table[c] = (int8_t)T;
-                    if (i == ql - 1) {
-                        if (a.score_row) a.score_row[row0 + j] = H;
-                        if (STATS) {
-                            if (a.matches_row) a.matches_row[row0 + j] = HM;
-                            if (a.similar_row) a.similar_row[row0 + j] = HS;
-                            if (a.length_row) a.length_row[row0 + j] = HL;
-                        }
-                    }
-                    if (j == rl - 1) {
-                        if (a.score_col) a.score_col[col0 + i] = H;
-                        if (STATS) {
-                            if (a.matches_col) a.matches_col[col0 + i] = HM;
-                            if (a.similar_col) a.similar_col[col0 + i] = HS;
-                            if (a.length_col) a.length_col[col0 + i] = HL;
-                        }
-                    }
-                }
-                const Cand c = {H, i, j, HM, HS, HL};
-                if (mode == PMX_MODE_SW) { if (better_sw(c, best_sw)) best_sw = c; }
-                else {
-                    if (i == ql - 1 && j == rl - 1) corner = c;
-                    if (i == ql - 1 && s2_end && c.H > best_row.H) best_row = c;   // j ascends: first max kept
-                    if (j == rl - 1 && s1_end && c.H > best_col.H) best_col = c;   // i ascends: first max kept
-                }
-                // state for the next column / the lane below
-                diagH = upH; diagM = upHM; diagS = upHS; diagL = upHL;
-                leftH = H; leftM = HM; leftS = HS; leftL = HL;
-                oH = H; oF = F; oHM = HM; oHS = HS; oHL = HL; oFM = FM; oFS = FS; oFL = FL;
-                if (lane == 63 && bandi + 1 < nbands) {
-                    bound[8LL * j + 0] = H; bound[8LL * j + 1] = F;
-                    if (STATS) {
-                        bound[8LL * j + 2] = HM; bound[8LL * j + 3] = HS; bound[8LL * j + 4] = HL;
-                        bound[8LL * j + 5] = FM; bound[8LL * j + 6] = FS; bound[8LL * j + 7] = FL;
-                    }
-                }
-            }
-    };
     // Score only, no band, every lane on a real cell away from the last column (steps 63 .. rlen - 2 of a band that is not the
     // last): none of the checked step's questions is open -- 25 instructions instead of ~100 (20 kbp x 20 kbp 358 -> 218 ms).
     // (Measured and dropped: fetching the row above 64 columns at a time one block ahead, 218 -> 267 ms; a barrier only every 16th
     // step, 218 -> 207 ms but slower banded batches: sixteen waves on one CU are bound by its four SIMDs, not by the barrier.)
     const bool lean_kind = !STATS && !OUT && band_w < 0 && a.bits != 8 && a.bits != 16;
-    auto do_step_lean = [&](int t) __attribute__((always_inline)) {
-        const int j = t - lane;
-        const int s = s_n;
-        s_n = mrow[sym_n];
-        sym_n = rs[j + 2];
-        int upH = lane_up(oH), upF = lane_up(oF);
-        if (lane == 0) {
-            if (bandi == 0) { upH = row_pen ? -(open + j * ext) : 0; upF = NEG_INF; }
-            else { upH = pb0; upF = pb1; pb0 = bound[8LL * (j + 1) + 0]; pb1 = bound[8LL * (j + 1) + 1]; }
-        }
-        const int F = max(upH - open, upF - ext);
-        E = max(leftH - open, E - ext);
-        int H = max(diagH + s, max(E, F));
-        if (mode == PMX_MODE_SW) {
-            H = max(H, 0);
-            if (H > best_sw.H) { best_sw.H = H; best_sw.i = i; best_sw.j = j; }     // (j ascends in a lane: the first maximum is kept)
-        }
-        diagH = upH; leftH = H; oH = H; oF = F;
-        if (lane == 63) { bound[8LL * j + 0] = H; bound[8LL * j + 1] = F; }
-    };
     // start step of every band: 66 steps (+ the shift of its column range) behind the band above, and not before the wave
     // that owns it has finished its previous band
     int *sched = reinterpret_cast<int *>(lds + a.mw_sched_off);        // [nbands] start steps, then the end step
@@ -652,10 +457,203 @@ void pmx_general_mw_kernel(const PmxGeneralArgs a)
     const int end = sched[nbands];
     int cb = wave, t = 0, t_end = 0, start = cb < nbands ? sched[cb] : 0x7fffffff;
     for (int gs = 0; gs < end; ++gs) {
-        if (gs == start) { band_init(cb); t = jlo; t_end = jhi + 1 + 63; }
+        if (gs == start) {
+            const int b = cb;
+            bandi = b;
+            i = bandi * 64 + lane;
+            row_ok = i < ql;
+            qsym = row_ok ? a.mapper[q[i]] : 0;
+            mrow = mat + (a.pssm ? (row_ok ? i : 0) : qsym) * msize;
+            // left boundary H(i,-1) and the diagonal seed H(i-1,-1)
+            leftH = col_pen ? -(open + i * ext) : 0;
+            leftM = 0; leftS = 0; leftL = col_pen ? i + 1 : 0;
+            diagH = (i == 0) ? 0 : (col_pen ? -(open + (i - 1) * ext) : 0);
+            diagM = 0; diagS = 0; diagL = (i == 0) ? 0 : (col_pen ? i : 0);
+            if (row_ok) { hmin = min(hmin, leftH); }
+            E = NEG_INF; EM = 0; ES = 0; EL = 0;
+            // what this lane hands to the lane below: H(i,j), F(i,j) and stats
+            oH = NEG_INF; oF = NEG_INF; oHM = 0; oHS = 0; oHL = 0; oFM = 0; oFS = 0; oFL = 0;
+
+            tdst = nullptr; ts = nullptr;
+            if (tlds) {
+                tdst = a.trace_table + tab0 + (long long)bandi * 64 * rl;
+                ts = tstage + ((uintptr_t)tdst & 15);          // same alignment mod 16 as the destination
+            }
+            // lane 0 reads the previous band's last row one column ahead of its use
+            pb0 = pb1 = pb2 = pb3 = pb4 = pb5 = pb6 = pb7 = 0;
+            if (lane == 0 && bandi > 0) {
+                pb0 = bound[0]; pb1 = bound[1];
+                if (STATS) { pb2 = bound[2]; pb3 = bound[3]; pb4 = bound[4]; pb5 = bound[5]; pb6 = bound[6]; pb7 = bound[7]; }
+            }
+            // Banded: only the columns some row of this 64-row band can reach are swept -- rows 64 b .. 64 b + 63 see columns
+            // [64 b + d - w, 64 b + 63 + d + w]; everything left and right of that range is outside the band for every row of the band,
+            // so the sweep may start there with "minus infinity" to its left.  Work per pair: qlen x (2 w + 190) instead of qlen x rlen.
+            jlo = 0; jhi = rl - 1; pjhi = rl - 1;                // this band's column range; the previous band's last column
+            if (band_w >= 0) {
+                jlo = max(0, bandi * 64 + band_d - band_w);
+                jhi = min(rl - 1, bandi * 64 + 63 + band_d + band_w);
+                pjhi = min(rl - 1, bandi * 64 - 1 + band_d + band_w);
+                if (jlo > 0) {                                    // the column left of the range is outside the band for all 64 rows ...
+                    leftH = NEG_INF; leftM = leftS = leftL = 0;
+                    diagH = NEG_INF; diagM = diagS = diagL = 0;
+                    if (lane == 0 && bandi == 0) {                // ... but row -1 is the boundary row, which keeps its values
+                        diagH = row_pen ? -(open + (jlo - 1) * ext) : 0;
+                        diagL = row_pen ? jlo : 0;
+                    }
+                    if (lane == 0 && bandi > 0 && jlo - 1 <= pjhi) {   // ... and (64 b - 1, jlo - 1) may lie inside the band: lane 0's first diagonal source
+                        diagH = bound[8LL * (jlo - 1) + 0];
+                        if (STATS) { diagM = bound[8LL * (jlo - 1) + 2]; diagS = bound[8LL * (jlo - 1) + 3]; diagL = bound[8LL * (jlo - 1) + 4]; }
+                    }
+                }
+                if (lane == 0 && bandi > 0 && jlo > 0) {          // the read-ahead of the previous band's row starts at jlo
+                    const bool in = jlo <= pjhi;
+                    pb0 = in ? bound[8LL * jlo + 0] : NEG_INF; pb1 = in ? bound[8LL * jlo + 1] : NEG_INF;
+                    if (STATS) { pb2 = in ? bound[8LL * jlo + 2] : 0; pb3 = in ? bound[8LL * jlo + 3] : 0; pb4 = in ? bound[8LL * jlo + 4] : 0;
+                                 pb5 = in ? bound[8LL * jlo + 5] : 0; pb6 = in ? bound[8LL * jlo + 6] : 0; pb7 = in ? bound[8LL * jlo + 7] : 0; }
+                }
+            }
+            // two-stage LDS pipeline: symbol of column j+2, score of column j+1
+            sym_n = rs[max(0, min(rl, jlo + 1 - lane))];
+            s_n = mrow[rs[max(0, min(rl, jlo - lane))]];
+            t = jlo; t_end = jhi + 1 + 63;
+        }
         if (gs >= start) {
-            if (lean_kind && bandi + 1 < nbands && t >= 63 && t <= rl - 2) do_step_lean(t);
-            else do_step(t);
+            if (lean_kind && bandi + 1 < nbands && t >= 63 && t <= rl - 2) {
+                const int j = t - lane;
+                const int s = s_n;
+                s_n = mrow[sym_n];
+                sym_n = rs[j + 2];
+                int upH = lane_up(oH), upF = lane_up(oF);
+                if (lane == 0) {
+                    if (bandi == 0) { upH = row_pen ? -(open + j * ext) : 0; upF = NEG_INF; }
+                    else { upH = pb0; upF = pb1; pb0 = bound[8LL * (j + 1) + 0]; pb1 = bound[8LL * (j + 1) + 1]; }
+                }
+                const int F = max(upH - open, upF - ext);
+                E = max(leftH - open, E - ext);
+                int H = max(diagH + s, max(E, F));
+                if (mode == PMX_MODE_SW) {
+                    H = max(H, 0);
+                    if (H > best_sw.H) { best_sw.H = H; best_sw.i = i; best_sw.j = j; }     // (j ascends in a lane: the first maximum is kept)
+                }
+                diagH = upH; leftH = H; oH = H; oF = F;
+                if (lane == 63) { bound[8LL * j + 0] = H; bound[8LL * j + 1] = F; }
+            } else {
+                const int j = t - lane;
+                const int s = s_n;                       // score for column j
+                const int rsym_cur = rs[max(0, min(rl, j))];
+                s_n = mrow[sym_n];
+                sym_n = rs[max(0, min(rl, j + 2))];
+                // --- values of the row above for column j (produced one step ago by lane-1) ---
+                int upH = lane_up(oH), upF = lane_up(oF);
+                int upHM = 0, upHS = 0, upHL = 0, upFM = 0, upFS = 0, upFL = 0;
+                if (STATS) {
+                    upHM = lane_up(oHM); upHS = lane_up(oHS); upHL = lane_up(oHL);
+                    upFM = lane_up(oFM); upFS = lane_up(oFS); upFL = lane_up(oFL);
+                }
+                const bool active = row_ok && j >= jlo && j <= jhi;
+                if (lane == 0 && j <= jhi) {
+                    if (bandi == 0) {
+                        upH = row_pen ? -(open + j * ext) : 0;
+                        upF = NEG_INF;
+                        upHM = upHS = 0; upHL = row_pen ? j + 1 : 0;
+                        upFM = upFS = upFL = 0;
+                        hmin = min(hmin, upH);
+                    } else {
+                        upH = pb0; upF = pb1;
+                        if (STATS) { upHM = pb2; upHS = pb3; upHL = pb4; upFM = pb5; upFS = pb6; upFL = pb7; }
+                        if (j + 1 < rl) {
+                            if (j + 1 <= pjhi) {
+                                pb0 = bound[8LL * (j + 1) + 0]; pb1 = bound[8LL * (j + 1) + 1];
+                                if (STATS) { pb2 = bound[8LL * (j + 1) + 2]; pb3 = bound[8LL * (j + 1) + 3]; pb4 = bound[8LL * (j + 1) + 4];
+                                             pb5 = bound[8LL * (j + 1) + 5]; pb6 = bound[8LL * (j + 1) + 6]; pb7 = bound[8LL * (j + 1) + 7]; }
+                            } else {                              // (banded) the previous band never reached that column: outside the band
+                                pb0 = NEG_INF; pb1 = NEG_INF;
+                                if (STATS) { pb2 = pb3 = pb4 = pb5 = pb6 = pb7 = 0; }
+                            }
+                        }
+                    }
+                }
+                if (active) {
+                    const int rsym = rsym_cur;
+                    int T = 0;
+                    int F, FM, FS, FL;
+                    {
+                        const int F_opn = upH - open, F_ext = upF - ext;
+                        if (F_opn > F_ext) { F = F_opn; FM = upHM; FS = upHS; FL = upHL + 1; T |= T_DIAG_F; }
+                        else { F = F_ext; FM = upFM; FS = upFS; FL = upFL + 1; T |= T_DEL_F; }
+                        if (F < NEG_INF) F = NEG_INF;
+                    }
+                    {
+                        const int E_opn = leftH - open, E_ext = E - ext;
+                        if (E_opn > E_ext) { E = E_opn; EM = leftM; ES = leftS; EL = leftL + 1; T |= T_DIAG_E; }
+                        else { E = E_ext; EL = EL + 1; T |= T_INS_E; }
+                        if (E < NEG_INF) E = NEG_INF;
+                    }
+                    const int H_dag = diagH + s;
+                    int H, HM, HS, HL;
+                    if (H_dag >= E && H_dag >= F) {
+                        H = H_dag; HM = diagM + (qsym == rsym); HS = diagS + (s > 0); HL = diagL + 1; T |= T_DIAG;
+                    } else if (F >= E) {
+                        H = F; HM = FM; HS = FS; HL = FL; T |= T_DEL;
+                    } else {
+                        H = E; HM = EM; HS = ES; HL = EL; T |= T_INS;
+                    }
+                    if (mode == PMX_MODE_SW && H <= 0) {
+                        H = 0; HM = HS = HL = 0; T &= ~(T_INS | T_DEL | T_DIAG);
+                    }
+                    if (band_w >= 0 && (j - i - band_d > band_w || j - i - band_d < -band_w)) {
+                        H = NEG_INF; E = NEG_INF; F = NEG_INF; HM = HS = HL = 0;
+                    }
+                    hmax = max(hmax, H);
+                    if (band_w < 0) hmin = min(hmin, H);
+
+                    if (OUT) {
+                        const long long c = tab0 + (long long)i * rl + j;
+                        if (a.score_table) a.score_table[c] = H;
+                        if (STATS) {
+                            if (a.matches_table) a.matches_table[c] = HM;
+                            if (a.similar_table) a.similar_table[c] = HS;
+                            if (a.length_table) a.length_table[c] = HL;
+                        }
+                        if (tlds) ts[lane * rl + j] = (unsigned char)T;
+                        else if (a.trace_table) a.trace_table[c] = (int8_t)T;
+                        if (i == ql - 1) {
+                            if (a.score_row) a.score_row[row0 + j] = H;
+                            if (STATS) {
+                                if (a.matches_row) a.matches_row[row0 + j] = HM;
+                                if (a.similar_row) a.similar_row[row0 + j] = HS;
+                                if (a.length_row) a.length_row[row0 + j] = HL;
+                            }
+                        }
+                        if (j == rl - 1) {
+                            if (a.score_col) a.score_col[col0 + i] = H;
+                            if (STATS) {
+                                if (a.matches_col) a.matches_col[col0 + i] = HM;
+                                if (a.similar_col) a.similar_col[col0 + i] = HS;
+                                if (a.length_col) a.length_col[col0 + i] = HL;
+                            }
+                        }
+                    }
+                    const Cand c = {H, i, j, HM, HS, HL};
+                    if (mode == PMX_MODE_SW) { if (better_sw(c, best_sw)) best_sw = c; }
+                    else {
+                        if (i == ql - 1 && j == rl - 1) corner = c;
+                        if (i == ql - 1 && s2_end && c.H > best_row.H) best_row = c;   // j ascends: first max kept
+                        if (j == rl - 1 && s1_end && c.H > best_col.H) best_col = c;   // i ascends: first max kept
+                    }
+                    // state for the next column / the lane below
+                    diagH = upH; diagM = upHM; diagS = upHS; diagL = upHL;
+                    leftH = H; leftM = HM; leftS = HS; leftL = HL;
+                    oH = H; oF = F; oHM = HM; oHS = HS; oHL = HL; oFM = FM; oFS = FS; oFL = FL;
+                    if (lane == 63 && bandi + 1 < nbands) {
+                        bound[8LL * j + 0] = H; bound[8LL * j + 1] = F;
+                        if (STATS) {
+                            bound[8LL * j + 2] = HM; bound[8LL * j + 3] = HS; bound[8LL * j + 4] = HL;
+                            bound[8LL * j + 5] = FM; bound[8LL * j + 6] = FS; bound[8LL * j + 7] = FL;
+                        }
+                    }
+                }
+            }
             if (++t == t_end) { cb += W; start = cb < nbands ? sched[cb] : 0x7fffffff; }
         }
         __syncthreads();                                   // (stores of this step are visible to the whole workgroup after it)
