@@ -116,3 +116,29 @@ def test_single_pair_trace_table_from_the_table_kernel(pkg, orc, mode):
             assert res.get_cigar(q, r) == orc.cigar(w), ctx
             tb = res.get_traceback_strings(q, r)
             assert (tb.query, tb.comparison, tb.reference) == orc.traceback_strings(w), ctx
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_trace_and_statistics_tables_of_long_pairs(pkg, orc, mode):
+    """Outputs of one long pair from the general kernel in its pipelined multi-wave form (references beyond the table kernel's
+    1 024 columns, queries of several 64-row bands): trace table bytes + CIGAR, and the four statistics tables with last rows /
+    columns, against the oracle."""
+    rng = np.random.default_rng(9500 + mode)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    q = random_seqs(rng, 1, 333, 333)[0]
+    r = mutate(rng, q, 0.1, 0.04) + random_seqs(rng, 1, 900, 900)[0]
+    mk = lambda: [pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).global_,
+                  pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).semi_global,
+                  pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).local][mode]()
+    w = orc.align(mode, q, r, 5, 2, om, stats=True, table=True, rowcol=True, trace=True)
+    tr = mk().use_trace().build().align(q, r)
+    got = np.asarray(tr.get_trace_table().as_slice()).reshape(len(q), len(r))
+    assert (got == w.trace_table).all() and tr.get_cigar(q, r) == orc.cigar(w)
+    st = mk().use_stats().use_table().build().align(q, r)
+    for t in ("score", "matches", "similar", "length"):
+        assert (np.asarray(getattr(st, "get_%s_table" % t)().as_slice()).reshape(len(q), len(r)) == getattr(w, t + "_table")).all(), t
+    rc = mk().use_stats().use_last_rowcol().build().align(q, r)
+    for t in ("score", "matches", "similar", "length"):
+        assert (np.asarray(getattr(rc, "get_%s_row" % t)()) == getattr(w, t + "_row")).all(), t
+        assert (np.asarray(getattr(rc, "get_%s_col" % t)()) == getattr(w, t + "_col")).all(), t
+    assert (st.get_score(), st.get_matches(), st.get_similar(), st.get_length()) == (w.score, w.matches, w.similar, w.length)
