@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -1200,6 +1201,24 @@ static int trace_ws_init()
 }
 
 // 0 done (asynchronously on st), 1 not eligible, <0 error
+// Upload progress of the calling host entry (pmx_align_profile_batch): reference slices still travelling on a copy stream.  A
+// device routine that works through the batch in chunks of its own waits, per chunk, only for the slices that chunk reads.
+struct UploadHook { int K = 0; int64_t hi[8]; hipEvent_t ev[8]; int waited[2] = {0, 0}; std::atomic<int> recorded{0}; std::atomic<int> failed{0}; };
+static thread_local UploadHook *g_upload = nullptr;
+static int upload_wait(int64_t upto /* references [0, upto) are about to be read */, hipStream_t st, int which /* 0 / 1: the stream's own progress */)
+{
+    UploadHook *u = g_upload;
+    if (!u) return 0;
+    int &w = u->waited[which];
+    while (w < u->K && (w == 0 || u->hi[w - 1] < upto)) {
+        while (u->recorded.load(std::memory_order_acquire) <= w && !u->failed.load()) std::this_thread::yield();   // (the uploading thread records the events)
+        if (u->failed.load()) { set_err("upload of the references failed"); return -1; }
+        HIP_OR_RET(hipStreamWaitEvent(st, u->ev[w], 0));
+        ++w;
+    }
+    return 0;
+}
+
 static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch &b,
                                  pmx_record_t *d_out, pmx_stats_t *d_stats, hipStream_t st)
 {
@@ -1242,6 +1261,7 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
         uint32_t *tb = (uint32_t *)((unsigned char *)tbuf + (two ? (size_t)(idx & 1) * cbytes : 0));
         const hipStream_t sws = (two && (idx & 1)) ? g_tws.aux : st;
         if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(sws, g_tws.walk_done[idx & 1], 0));    // this buffer's previous walk is done
+        if (!b.perm && upload_wait(c0 + bk.n, sws, sws == st ? 0 : 1)) return -1;                  // (host entry: this chunk's references are up)
         int rc = pmx_launch_nwsgq_trace(variant, bk, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, out_k, tb, Tmax, sws);
         if (rc) { set_err("shared-profile traceback sweep failed (%d)", rc); return rc < 0 ? rc : -1; }
         hipStream_t ws = st;
@@ -1346,6 +1366,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         if (rc < 0) return rc;
         if (rc == 0) return 0;
     }
+    if (upload_wait(INT64_MAX, st, 0)) return -1;             // (host entry with a sliced upload: every other path reads the whole batch)
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
             if (want == PMX_WANT_STATS && cfg->width != 8 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
@@ -1652,6 +1673,37 @@ extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_p
     }
     HIP_OR_RET(hipMemcpyAsync(dro.p, roff, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s_copy));
     const int wild = profile_has_wildcard(profile);
+    if (stats && !(cfg->want & PMX_WANT_SORTED) && rbytes >= ((size_t)64 << 20)) {
+        // Statistics of the profile arm are counted along a traceback that already works through the references in chunks of
+        // its own (tens of thousands per launch, two launches in flight): cutting the batch into slices as below would shrink
+        // those launches.  One call instead; the upload goes in eight slices and every chunk waits only for the slices it reads.
+        UploadHook hook; hook.K = 8;
+        for (int sl = 0; sl < 8; ++sl) { hook.hi[sl] = n * (sl + 1) / 8; hook.ev[sl] = s_up[sl]; }
+        // (copies from pageable memory block the issuing thread: a helper issues them, this thread queues the kernels meanwhile)
+        const hipStream_t copy_stream = s_copy;               // (thread-local objects of THIS thread: the helper gets them by value)
+        uint8_t *const dr_base = dr.p;
+        std::thread up([&hook, copy_stream, dr_base, dev, n, roff, rbuf]() {
+            if (hipSetDevice(dev) != hipSuccess) { hook.failed.store(1); return; }
+            for (int sl = 0; sl < 8; ++sl) {
+                const int64_t a = n * sl / 8, e = n * (sl + 1) / 8;
+                hipError_t er = e > a ? hipMemcpyAsync(dr_base + roff[a], rbuf + roff[a], (size_t)(roff[e] - roff[a]), hipMemcpyHostToDevice, copy_stream) : hipSuccess;
+                if (er == hipSuccess) er = hipEventRecord(hook.ev[sl], copy_stream);
+                if (er != hipSuccess) { hook.failed.store(1); return; }
+                hook.recorded.store(sl + 1, std::memory_order_release);
+            }
+        });
+        g_upload = &hook;
+        const int rc = run_batch_device(cfg, n, dq.p, nullptr, profile->s1Len, dr.p, dro.p, profile->s1Len, mr,
+                                        drec.p, dst.p, s_comp, wild);
+        g_upload = nullptr;
+        up.join();
+        if (!rc && hook.failed.load()) { (void)hipStreamSynchronize(s_comp); set_err("upload of the references failed"); return -1; }
+        if (rc) { (void)hipStreamSynchronize(s_comp); (void)hipStreamSynchronize(s_copy); return rc; }
+        HIP_OR_RET(hipStreamSynchronize(s_comp));
+        HIP_OR_RET(hipMemcpy(out, drec.p, sizeof(pmx_record_t) * (size_t)n, hipMemcpyDeviceToHost));
+        HIP_OR_RET(hipMemcpy(stats_out, dst.p, sizeof(pmx_stats_t) * (size_t)n, hipMemcpyDeviceToHost));
+        return 0;
+    }
     for (int sl = 0; sl < K; ++sl) {
         const int64_t a = lo[sl], e = lo[sl + 1];
         if (e <= a) continue;

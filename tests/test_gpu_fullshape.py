@@ -365,3 +365,34 @@ def test_host_entry_large_batch_guards(pkg, orc):
             al.align_batch_packed(qbuf, off, rbuf[: int(bad[-1]) if bad[-1] > 0 else 1], bad)
     with pytest.raises(pkg.BatchError):
         al.align_batch_packed(qbuf, off, rbuf, off, out=np.zeros(n - 1, dtype=pkg.RECORD_DTYPE))
+
+
+def test_profile_host_entry_uploads_behind_the_kernels(pkg, orc):
+    """pmx_align_profile_batch with more than 64 MB of references: (a) statistics of the profile arm (config 3's shape) -- one
+    device call whose traceback chunks wait only for the reference slices they read, uploaded by a helper thread; (b) the plain
+    score form in byte-balanced slices.  Records and statistics equal the device entry's, a sample equals the oracle's."""
+    import torch
+    n = 15000
+    q, rbuf, roff = wl.make_cfg3(n, rank=3)
+    assert int(roff[-1]) > (64 << 20)
+    pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    al = pkg.Aligner.new().profile(pkg.Profile.new(q, True, pm)).matrix(pm).gap_open(11).gap_extend(1).solution_width(16).build()
+    rec, st = al.align_batch_packed(None, None, rbuf, roff)
+    assert "packed trace" in pkg.lib.pmx_last_kernel().decode()
+    dev = torch.device("cuda", 0)
+    d_r, d_o = torch.from_numpy(rbuf).to(dev), torch.from_numpy(roff).to(dev)
+    d_out = torch.zeros((n, 4), dtype=torch.int32, device=dev); d_st = torch.zeros((n, 3), dtype=torch.int32, device=dev)
+    cfg = al._config()
+    pkg.align_profile_batch_device(cfg, al._profile, n, d_r.data_ptr(), d_o.data_ptr(), int((roff[1:] - roff[:-1]).max()),
+                                   d_out.data_ptr(), d_st.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    o, s = d_out.cpu().numpy(), d_st.cpu().numpy()
+    assert (rec["score"] == o[:, 0]).all() and (rec["end_query"] == o[:, 1]).all() and (rec["end_ref"] == o[:, 2]).all()
+    assert (st["matches"] == s[:, 0]).all() and (st["similar"] == s[:, 1]).all() and (st["length"] == s[:, 2]).all()
+    idx = np.arange(0, n, 131)
+    want = orc.align_stats_sample(orc.NW, idx, None, None, rbuf, roff, 11, 1, om, bits=16, shared_query=q)
+    assert (rec["score"][idx] == want[:, 0]).all() and (st["matches"][idx] == want[:, 3]).all() and (st["length"][idx] == want[:, 5]).all()
+    al0 = pkg.Aligner.new().local().profile(pkg.Profile.new(q, False, pm)).matrix(pm).gap_open(11).gap_extend(1).build()
+    got = al0.align_batch_packed(None, None, rbuf, roff)
+    want0 = orc.align_stats_sample(orc.SW, idx, None, None, rbuf, roff, 11, 1, om, shared_query=q)
+    assert (got["score"][idx] == want0[:, 0]).all() and (got["end_ref"][idx] == want0[:, 2]).all()
