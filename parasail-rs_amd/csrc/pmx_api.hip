@@ -1390,23 +1390,38 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
             int variant = 0, Tmax = 0; size_t tbytes = 0;
             if (pmx_trace16_plan(bt, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes) == 0 && variant >= 10) {
                 double budget = 8e9;
-                { size_t fb = 0, tb = 0; if (hipMemGetInfo(&fb, &tb) == hipSuccess && 0.3 * (double)fb < budget) budget = 0.3 * (double)fb; }
+                { size_t fb = 0, tb = 0; if (hipMemGetInfo(&fb, &tb) == hipSuccess && 0.15 * (double)fb < budget) budget = 0.15 * (double)fb; }
                 const double per_pair = (double)tbytes / (double)n + 1.0;
-                int64_t chunk = (int64_t)(budget / per_pair) / 64 * 64;
+                int64_t nchunks = (int64_t)((double)tbytes / budget) + 1;
+                if (nchunks < 2 && n >= 16384) nchunks = 2;            // two chunks at least: the walk of one runs beside the sweep of the next
+                int64_t chunk = ((n + nchunks - 1) / nchunks + 63) / 64 * 64;
+                if ((double)chunk * per_pair > budget) chunk = (int64_t)(budget / per_pair) / 64 * 64;
                 if (chunk < 64) chunk = 64;
                 if (chunk > n) chunk = n;
                 bt.n = chunk;
                 (void)pmx_trace16_plan(bt, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &tbytes);
+                const size_t cbytes = (tbytes + 255) & ~(size_t)255;
+                const bool two = chunk < n;
+                if (two && trace_ws_init()) return -1;
                 uint32_t *tbuf = nullptr;
-                if (scratch_reserve(tbytes, (void **)&tbuf, SCR_TRACE)) return -1;
-                for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+                if (scratch_reserve(cbytes * (two ? 2 : 1), (void **)&tbuf, SCR_TRACE)) return -1;
+                // as in the batch CIGAR entry: two trace buffers, the counting walk of chunk c on the walk stream beside the sweep of
+                // chunk c + 1, sweeps alternating between the caller's stream and an internal one
+                if (two) { HIP_OR_RET(hipEventRecord(g_tws.start, st)); HIP_OR_RET(hipStreamWaitEvent(g_tws.aux, g_tws.start, 0)); }
+                int idx = 0;
+                for (int64_t c0 = 0; c0 < n; c0 += chunk, ++idx) {
                     PmxBatch bc = bt;
                     bc.n = (n - c0 < chunk) ? n - c0 : chunk;
                     bc.qoff = d_qoff + c0; bc.roff = d_roff + c0;
-                    const int rc = pmx_launch_trace16(variant, bc, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out + c0, tbuf, Tmax,
-                                                      nullptr, nullptr, nullptr, nullptr, st, d_stats_out + c0);
+                    const hipStream_t sws = (two && (idx & 1)) ? g_tws.aux : st;
+                    if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(sws, g_tws.walk_done[idx & 1], 0));
+                    PmxWalkSplit sp = {two ? g_tws.walk : st, g_tws.sweep_done[idx & 1], two ? g_tws.walk_done[idx & 1] : nullptr, 0, nullptr};
+                    const int rc = pmx_launch_trace16(variant, bc, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out + c0,
+                                                      (uint32_t *)((unsigned char *)tbuf + (two ? (size_t)(idx & 1) * cbytes : 0)), Tmax,
+                                                      nullptr, nullptr, nullptr, nullptr, sws, d_stats_out + c0, two ? &sp : nullptr);
                     if (rc) { set_err("stats-by-traceback launch failed (%d)", rc); return rc < 0 ? rc : -1; }
                 }
+                if (two) HIP_OR_RET(hipStreamWaitEvent(st, g_tws.walk_done[(idx - 1) & 1], 0));
                 g_last_kernel = variant >= 20 ? "pmx_sw16_kernel/packed trace + pmx_walkp_kernel/stats" : "pmx_nwsg16v_kernel/packed trace + pmx_walkp_kernel/stats";
                 return 0;
             }
