@@ -9,7 +9,10 @@
  * Trace states (flag names pinned by src/alignment/table.rs:127-142): INS = the E table (horizontal move: consumes a character
  * of s2 / the reference, gap character in the query line), DEL = the F table (vertical move: consumes a character of s1 / the
  * query).  Chosen letters: SAM sense with query = s1, reference = s2 -- consuming only the reference is 'D', consuming only the
- * query is 'I'.  Evidence for this choice (outside the reference tree, from memory): downstream users hand (read, reference) to
+ * query is 'I'.  The other orientation (state INS -> 'I', state DEL -> 'D', which a round-1 review note believes upstream's
+ * cigar.c uses) is available WITHOUT a rebuild: set PMX_CIGAR_SWAP_ID=1 in the environment of the calling process and every
+ * CIGAR handed out (packed ops of parasail_result_get_cigar / parasail_ssw, decoded text, batch CIGAR text) has I and D
+ * exchanged; the defines below are the compiled default ("CIGAR letters").  Evidence for this choice (outside the reference tree, from memory): downstream users hand (read, reference) to
  * parasail as (s1, s2) and feed the decoded CIGAR to SAM/BAM writers unchanged apart from clipping.  [UNPINNED]
  */
 #ifndef PMX_CONVENTIONS_H

@@ -841,9 +841,11 @@ class Aligner:
             raise BatchError(lib.pmx_last_error().decode())
         # a view of the callee's malloc block (no copy); released with pmx_free when the array goes away
         nbytes = int(coff[n])
-        holder = _OwnedBuffer(cbuf)
-        text = np.frombuffer((C.c_ubyte * max(nbytes, 1)).from_address(cbuf.value), dtype=np.uint8, count=nbytes)
-        text = _with_owner(text, holder)
+        # The owner hangs on the ctypes array, the ULTIMATE base of every numpy view (numpy collapses the base chain of
+        # derived arrays down to it: np.asarray(text), text.view(np.ndarray) and slices all keep the block alive).
+        raw = (C.c_ubyte * max(nbytes, 1)).from_address(cbuf.value)
+        raw._pmx_owner = _OwnedBuffer(cbuf)
+        text = np.frombuffer(raw, dtype=np.uint8, count=nbytes)
         return out, text, coff
 
 
@@ -860,16 +862,6 @@ class _OwnedBuffer:
                 self.ptr = None
         except Exception:
             pass
-
-
-class _OwnedArray(np.ndarray):
-    pass
-
-
-def _with_owner(arr, owner):
-    out = arr.view(_OwnedArray)
-    out._pmx_owner = owner
-    return out
 
 
 def pack(seqs):

@@ -12,6 +12,7 @@
 #include "pmx_matrices.h"
 
 #include <cctype>
+#include <dlfcn.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +22,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 #include <utility>
@@ -178,17 +180,29 @@ static const parasail_matrix_t *lookup_in_matrix_dir(const std::string &lname)
     for (char c : lname) if (!(isalnum((unsigned char)c) || c == '_' || c == '-' || c == '.')) return nullptr;    // a name, not a path
     if (lname.empty() || lname[0] == '.') return nullptr;
     std::lock_guard<std::mutex> lk(mx);
-    auto it = cache.find(lname);
+    // $PMX_MATRIX_DIR, else the directory shipped beside the library: <libdir>/../matrices (parasail-rs_amd/matrices in this tree)
+    std::string dir;
+    const char *env = pmx_env("PMX_MATRIX_DIR");
+    if (env && *env) dir = env;
+    else {
+        Dl_info info;
+        if (dladdr((const void *)&lookup_in_matrix_dir, &info) && info.dli_fname) {
+            const std::string so(info.dli_fname);
+            const size_t slash = so.rfind('/');
+            dir = (slash == std::string::npos ? std::string(".") : so.substr(0, slash)) + "/../matrices";
+        }
+    }
+    if (dir.empty()) return nullptr;
+    const std::string key = dir + "\n" + lname;               // hits AND misses are remembered per directory (a miss costs three fopen calls)
+    auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    const char *dir = pmx_env("PMX_MATRIX_DIR");
-    if (!dir || !*dir) return nullptr;
     parasail_matrix_t *m = nullptr;
     for (const char *suffix : {"", ".txt", ".mat"}) {
-        const std::string path = std::string(dir) + "/" + lname + suffix;
+        const std::string path = dir + "/" + lname + suffix;
         m = parasail_matrix_from_file(path.c_str());
         if (m) break;
     }
-    if (!m) return nullptr;
+    if (!m) { cache[key] = nullptr; return nullptr; }
     MatrixBox *b = nullptr;
     {   // from here on it is a built-in: out of the table of caller-owned matrices, not writable
         std::lock_guard<std::mutex> lk2(g_mx_mutex);
@@ -197,7 +211,7 @@ static const parasail_matrix_t *lookup_in_matrix_dir(const std::string &lname)
     }
     if (b) { b->name = lname; b->m.name = b->name.c_str(); }
     m->user_matrix = nullptr;
-    cache[lname] = m;
+    cache[key] = m;
     return m;
 }
 
@@ -209,7 +223,7 @@ extern "C" const parasail_matrix_t *parasail_matrix_lookup(const char *matrixnam
     std::string s(matrixname);
     for (auto &c : s) c = (char)tolower((unsigned char)c);
     if (s == "blosum62") return &g_blosum62;
-    if (s == "nuc44") return &g_nuc44;
+    if (s == "nuc44" || s == "dnafull") return &g_nuc44;      // EDNAFULL is the NUC.4.4 table under EMBOSS's name
     return lookup_in_matrix_dir(s);
 }
 
@@ -496,14 +510,25 @@ struct SingleWs { void *dev = nullptr; void *pin = nullptr; size_t cap = 0; int 
 static thread_local SingleWs g_single;
 // one device block per host thread for the one-pair calls that return tables (carved up per call: a dozen hipMalloc / hipFree
 // per call cost more than the kernel)
+// The block is kept between calls only up to SINGLE_BIG_KEEP: one 20 kbp x 20 kbp table call would otherwise pin gigabytes of HBM
+// per host thread for the life of the process (the batch entries size their chunks from the free memory they find).
+static const size_t SINGLE_BIG_KEEP = (size_t)256 << 20;
 static void single_big_reserve(size_t bytes)
 {
     int dev = 0; HIP_OR_DIE(hipGetDevice(&dev));
     if (g_single.bigdev == dev && g_single.bigcap >= bytes) return;
     if (g_single.big) (void)hipFree(g_single.big);
-    const size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
+    g_single.big = nullptr; g_single.bigcap = 0; g_single.bigdev = -1;
+    const size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2 <= SINGLE_BIG_KEEP ? bytes + bytes / 2 : bytes;
     HIP_OR_DIE(hipMalloc(&g_single.big, cap));
     g_single.bigcap = cap; g_single.bigdev = dev;
+}
+static void single_big_trim()
+{
+    if (g_single.big && g_single.bigcap > SINGLE_BIG_KEEP) {
+        (void)hipFree(g_single.big);
+        g_single.big = nullptr; g_single.bigcap = 0; g_single.bigdev = -1;
+    }
 }
 static void single_reserve(size_t bytes)
 {
@@ -665,6 +690,7 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
         if (!res->trace) die("malloc", hipSuccess);
         HIP_OR_DIE(hipMemcpy(res->trace, dtrace.p, cells, hipMemcpyDeviceToHost));
     }
+    single_big_trim();
     return res;
 }
 
@@ -931,6 +957,14 @@ static std::string walk_ops(const parasail_result_t *res, const char *seqA, int 
 }
 
 static const char BAM_OPS[] = "MIDNSHP=X";
+// The letters of the two gap states are not pinned by anything the reference holds (include/pmx_conventions.h).  The compiled
+// default can be exchanged at run time, without a rebuild, by a caller who holds real parasail output that says otherwise:
+// PMX_CIGAR_SWAP_ID=1 swaps I and D in everything handed out (packed ops of get_cigar / ssw, decoded text, batch CIGAR text).
+int pmx_cigar_swapped()
+{
+    const char *v = pmx_env("PMX_CIGAR_SWAP_ID");
+    return v && *v && strcmp(v, "0") != 0;
+}
 
 extern "C" parasail_cigar_t *parasail_result_get_cigar(parasail_result_t *result, const char *seqA, int lena,
                                                        const char *seqB, int lenb, const parasail_matrix_t *matrix)
@@ -942,10 +976,12 @@ extern "C" parasail_cigar_t *parasail_result_get_cigar(parasail_result_t *result
     c->seq = (uint32_t *)malloc(sizeof(uint32_t) * (ops.size() + 1));
     if (!c->seq) { free(c); return nullptr; }
     size_t k = 0; int n = 0;
+    const int swap = pmx_cigar_swapped();
     while (k < ops.size()) {
         size_t run = 1;
         while (k + run < ops.size() && ops[k + run] == ops[k]) ++run;
-        const uint32_t op = (uint32_t)(strchr(BAM_OPS, ops[k]) - BAM_OPS);
+        uint32_t op = (uint32_t)(strchr(BAM_OPS, ops[k]) - BAM_OPS);
+        if (swap && (op == 1u || op == 2u)) op ^= 3u;             // I (1) <-> D (2)
         c->seq[n++] = ((uint32_t)run << 4) | op;
         k += run;
     }
@@ -1147,7 +1183,8 @@ static int general_batch(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
     const bool fits = pmx_general_lds_fits(dm.d.msize, dm.d.msize, max_rlen);
     const size_t rs_stride = fits ? 0 : (((size_t)max_rlen + 8 + 15) & ~(size_t)15);
     const size_t per_pair = stride * sizeof(int32_t) + rs_stride;
-    int64_t chunk = (int64_t)(2e9 / (double)per_pair);
+    const char *cb = pmx_env("PMX_TABLE_CHUNK_BYTES");
+    int64_t chunk = (int64_t)((cb && atof(cb) > 0 ? atof(cb) : 2e9) / (double)per_pair);
     if (chunk < 1) chunk = 1;
     if (chunk > n) chunk = n;
     void *bound = nullptr;
@@ -1503,10 +1540,15 @@ static LenScan scan_lengths(int64_t n, const int64_t *qoff, const int64_t *roff)
         host_maxlens(e - a, qoff + a, &part[t].mq, &part[t].bad);
         host_maxlens(e - a, roff + a, &part[t].mr, &part[t].bad, &part[t].mnr);
     };
+    // (thread creation can fail -- a process at its thread limit: std::system_error must not unwind through the C ABI; the
+    //  parts without a helper are scanned here)
     std::thread th[3];
-    for (int t = 1; t < T; ++t) th[t - 1] = std::thread(work, t);
+    bool started[3] = {false, false, false};
+    for (int t = 1; t < T; ++t) {
+        try { th[t - 1] = std::thread(work, t); started[t - 1] = true; } catch (const std::system_error &) {}
+    }
     work(0);
-    for (int t = 1; t < T; ++t) th[t - 1].join();
+    for (int t = 1; t < T; ++t) { if (started[t - 1]) th[t - 1].join(); else work(t); }
     LenScan r = part[0];
     for (int t = 1; t < T; ++t) {
         r.mq = std::max(r.mq, part[t].mq); r.mr = std::max(r.mr, part[t].mr); r.mnr = std::min(r.mnr, part[t].mnr); r.bad |= part[t].bad;
@@ -1534,8 +1576,10 @@ static int host_batch(const pmx_config_t *cfg, int64_t n,
     // the length scan runs beside the first transfers (it needs the host only; the offsets go up meanwhile)
     LenScan ls;
     std::future<void> scan;
-    if (n >= 262144) scan = std::async(std::launch::async, [&]() { ls = scan_lengths(n, qoff, roff); });
-    else ls = scan_lengths(n, qoff, roff);
+    if (n >= 262144) {
+        try { scan = std::async(std::launch::async, [&]() { ls = scan_lengths(n, qoff, roff); }); }
+        catch (const std::system_error &) { ls = scan_lengths(n, qoff, roff); }          // no helper thread to be had: scan inline
+    } else ls = scan_lengths(n, qoff, roff);
     struct ScanJoin { std::future<void> &f; ~ScanJoin() { if (f.valid()) f.wait(); } } scan_join{scan};     // (early returns)
     if (qoff[0] != 0 || roff[0] != 0) { set_err("offset arrays must start at 0"); return -1; }
     if (qoff[n] <= 0 || roff[n] <= 0 || qoff[n] > ((int64_t)1 << 40) || roff[n] > ((int64_t)1 << 40)) { set_err("bad offset arrays"); return -1; }
@@ -1697,7 +1741,7 @@ extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_p
         // (copies from pageable memory block the issuing thread: a helper issues them, this thread queues the kernels meanwhile)
         const hipStream_t copy_stream = s_copy;               // (thread-local objects of THIS thread: the helper gets them by value)
         uint8_t *const dr_base = dr.p;
-        std::thread up([&hook, copy_stream, dr_base, dev, n, roff, rbuf]() {
+        auto upload = [&hook, copy_stream, dr_base, dev, n, roff, rbuf]() {
             if (hipSetDevice(dev) != hipSuccess) { hook.failed.store(1); return; }
             for (int sl = 0; sl < 8; ++sl) {
                 const int64_t a = n * sl / 8, e = n * (sl + 1) / 8;
@@ -1706,12 +1750,14 @@ extern "C" int pmx_align_profile_batch(const pmx_config_t *cfg, const parasail_p
                 if (er != hipSuccess) { hook.failed.store(1); return; }
                 hook.recorded.store(sl + 1, std::memory_order_release);
             }
-        });
+        };
+        std::thread up;
+        try { up = std::thread(upload); } catch (const std::system_error &) { upload(); }     // no helper: the copies are issued first
         g_upload = &hook;
         const int rc = run_batch_device(cfg, n, dq.p, nullptr, profile->s1Len, dr.p, dro.p, profile->s1Len, mr,
                                         drec.p, dst.p, s_comp, wild);
         g_upload = nullptr;
-        up.join();
+        if (up.joinable()) up.join();
         if (!rc && hook.failed.load()) { (void)hipStreamSynchronize(s_comp); set_err("upload of the references failed"); return -1; }
         if (rc) { (void)hipStreamSynchronize(s_comp); (void)hipStreamSynchronize(s_copy); return rc; }
         HIP_OR_RET(hipStreamSynchronize(s_comp));
@@ -1873,7 +1919,8 @@ extern "C" int pmx_align_batch_table_device(const pmx_config_t *cfg, int64_t n,
     const bool fits = pmx_general_lds_fits(dm.d.msize, dm.d.msize, max_rlen);
     const size_t rs_stride = fits ? 0 : (((size_t)max_rlen + 8 + 15) & ~(size_t)15);
     const size_t per_pair = stride * sizeof(int32_t) + rs_stride;
-    int64_t chunk = (int64_t)(2e9 / (double)per_pair);
+    const char *cb = pmx_env("PMX_TABLE_CHUNK_BYTES");
+    int64_t chunk = (int64_t)((cb && atof(cb) > 0 ? atof(cb) : 2e9) / (double)per_pair);
     if (chunk < 1) chunk = 1;
     if (chunk > n) chunk = n;
     void *bound = nullptr;
@@ -1891,7 +1938,6 @@ extern "C" int pmx_align_batch_table_device(const pmx_config_t *cfg, int64_t n,
         a.rec = (d_out ? d_out : tmp_rec.p) + c0;
         a.tab_off = d_tab_off ? d_tab_off + c0 : nullptr; a.score_table = d_score_table;
         a.score_row = d_score_row; a.score_col = d_score_col;
-        if (m == 1 && n > 1) { set_err("general-kernel table batches need chunks of at least two pairs"); return -1; }
         rc = pmx_launch_general(a, false, st);
         if (rc) { set_err("general kernel launch failed (%d)", rc); return rc < 0 ? rc : -1; }
     }
@@ -2394,7 +2440,8 @@ static int multi_run(const pmx_config_t *cfg, const parasail_profile_t *profile,
     std::lock_guard<std::mutex> call_lock(g_pool_mx);          // one multi-GPU call at a time per process (the workers are shared)
     while ((int)g_pool.size() < ndev) {
         ShardWorker *w = new ShardWorker;
-        w->th = std::thread([w] { w->loop(); });
+        try { w->th = std::thread([w] { w->loop(); }); }
+        catch (const std::system_error &e) { delete w; set_err("cannot start a host thread for shard %d: %s", (int)g_pool.size(), e.what()); return -1; }
         w->th.detach();
         g_pool.push_back(w);
     }

@@ -186,5 +186,8 @@ int pmx_launch_text_offsets(const int32_t *textlen, long long n, int64_t *text_o
 int pmx_launch_cigar_render_slots(const uint32_t *ops, const int64_t *qoff, const int64_t *roff, long long ops_base, const int32_t *nops,
                                   const int64_t *text_off, char *text, long long capacity, long long n, hipStream_t stream);
 
+// Run-time CIGAR letter convention (switch PMX_CIGAR_SWAP_ID, read per call): 1 = exchange I and D in everything handed out.
+int pmx_cigar_swapped();
+
 // Collect the indices of records whose flags intersect `mask`: list[0..*count) (device), any order.
 int pmx_launch_collect_saturated(const pmx_record_t *rec, long long n, int64_t *list, int *count, int mask, hipStream_t stream);

@@ -96,8 +96,8 @@ void pmx_general_kernel(const PmxGeneralArgs a)
     unsigned char *tstage = rs_lds + (((size_t)a.max_rlen + 8 + 15) & ~(size_t)15);
     const bool tlds = OUT && a.trace_table && a.trace_lds;
     const long long tab0 = a.tab_off ? a.tab_off[pair] : 0;
-    const long long row0 = (a.n > 1 || a.index) ? rb : 0;     // row outputs packed like the references
-    const long long col0 = (a.n > 1 && a.qoff) ? qb : (a.qoff ? 0 : pair * (long long)ql);
+    const long long row0 = rb;                                // row outputs packed like the references (a one-pair call has rb == 0;
+    const long long col0 = a.qoff ? qb : pair * (long long)ql;   //  a one-pair CHUNK of a batch keeps its place), columns like the queries
     int32_t *bound = a.bound + (long long)blockIdx.x * a.bound_stride;
 
     const int mode = a.mode, open = a.open, ext = a.ext, band_w = a.band;
@@ -399,8 +399,8 @@ void pmx_general_mw_kernel(const PmxGeneralArgs a)
     unsigned char *tstage = rs_lds + (((size_t)a.max_rlen + 8 + 15) & ~(size_t)15);
     const bool tlds = false;                                   // (no LDS staging of trace bytes in this form)
     const long long tab0 = a.tab_off ? a.tab_off[pair] : 0;
-    const long long row0 = (a.n > 1 || a.index) ? rb : 0;     // row outputs packed like the references
-    const long long col0 = (a.n > 1 && a.qoff) ? qb : (a.qoff ? 0 : pair * (long long)ql);
+    const long long row0 = rb;                                // row outputs packed like the references (a one-pair call has rb == 0;
+    const long long col0 = a.qoff ? qb : pair * (long long)ql;   //  a one-pair CHUNK of a batch keeps its place), columns like the queries
     int32_t *bound = a.bound + (long long)blockIdx.x * a.bound_stride;
 
     const int mode = a.mode, open = a.open, ext = a.ext, band_w = a.band;
@@ -873,9 +873,11 @@ __global__ void pmx_cigar_textlen_kernel(const uint32_t *ops, const int64_t *ops
     for (int t = 0; t < nops[k]; ++t) len += pmx_digits(src[t] >> 4) + 1;
     textlen[k] = len;
 }
+// `swap`: the run-time convention switch PMX_CIGAR_SWAP_ID (include/pmx_conventions.h) -- letters I and D exchanged in the text
 __global__ void pmx_cigar_render_kernel(const uint32_t *ops, const int64_t *ops_off, const int32_t *nops,
-                                        const int64_t *text_off, char *text, long long n)
+                                        const int64_t *text_off, char *text, long long n, int swap)
 {
+    const char *letters = swap ? "MDINSHP=X" : "MIDNSHP=X";
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint32_t *src = ops + ops_off[k];
@@ -885,7 +887,7 @@ __global__ void pmx_cigar_render_kernel(const uint32_t *ops, const int64_t *ops_
         uint32_t v = o >> 4;
         const int d = pmx_digits(v);
         for (int x = d - 1; x >= 0; --x) { dst[x] = (char)('0' + v % 10); v /= 10; }
-        dst[d] = "MIDNSHP=X"[o & 0xF];
+        dst[d] = letters[o & 0xF];
         dst += d + 1;
     }
 }
@@ -900,7 +902,8 @@ int pmx_launch_cigar_render(const uint32_t *ops, const int64_t *ops_off, const i
                             const int64_t *text_off, char *text, long long n, hipStream_t stream)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(pmx_cigar_render_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, ops, ops_off, nops, text_off, text, n);
+    hipLaunchKernelGGL(pmx_cigar_render_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, ops, ops_off, nops, text_off, text, n,
+                       pmx_cigar_swapped());
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
@@ -911,8 +914,9 @@ int pmx_launch_cigar_render(const uint32_t *ops, const int64_t *ops_off, const i
 // base plus a prefix sum of the widths over the eight lanes.  A pair whose text would cross `capacity` is skipped
 // (the caller sees text_off[n] > capacity).
 __global__ void pmx_cigar_render_slots_kernel(const uint32_t *ops, const int64_t *qoff, const int64_t *roff, long long ops_base,
-                                              const int32_t *nops, const int64_t *text_off, char *text, long long capacity, long long n)
+                                              const int32_t *nops, const int64_t *text_off, char *text, long long capacity, long long n, int swap)
 {
+    const char *letters = swap ? "MDINSHP=X" : "MIDNSHP=X";
     const long long k = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     const int l = threadIdx.x & 7;
     if (k >= n) return;
@@ -933,7 +937,7 @@ __global__ void pmx_cigar_render_slots_kernel(const uint32_t *ops, const int64_t
         if (t < cnt) {
             char *dst = text + base + inc - w;
             for (int x = d - 1; x >= 0; --x) { dst[x] = (char)('0' + v % 10); v /= 10; }
-            dst[d] = "MIDNSHP=X"[o & 0xF];
+            dst[d] = letters[o & 0xF];
         }
         base += __shfl(inc, 7, 8);
     }
@@ -944,7 +948,7 @@ int pmx_launch_cigar_render_slots(const uint32_t *ops, const int64_t *qoff, cons
 {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(pmx_cigar_render_slots_kernel, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, stream,
-                       ops, qoff, roff, ops_base, nops, text_off, text, capacity, n);
+                       ops, qoff, roff, ops_base, nops, text_off, text, capacity, n, pmx_cigar_swapped());
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

@@ -239,6 +239,32 @@ def test_matrix_lookup_resolves_documented_names_from_a_directory(pkg, tmp_path,
             pkg.Matrix.from_name(bad)
 
 
+def test_matrix_lookup_default_directory_and_aliases(pkg, monkeypatch):
+    """Without $PMX_MATRIX_DIR the library looks in <libdir>/../matrices (shipped with the package); misses are remembered per
+    directory; `dnafull` is the NUC.4.4 table under its EMBOSS name."""
+    import shutil
+    monkeypatch.delenv("PMX_MATRIX_DIR", raising=False)
+    assert (pkg.Matrix.from_name("dnafull").to_numpy() == pkg.Matrix.from_name("nuc44").to_numpy()).all()
+    shipped = os.path.join(ROOT, "parasail-rs_amd", "matrices")
+    assert os.path.isdir(shipped)
+    name = "pmxtestonly77"
+    with pytest.raises(pkg.FailedLookup):
+        pkg.Matrix.from_name(name)
+    dst = os.path.join(shipped, name + ".txt")
+    try:
+        shutil.copy(os.path.join(ROOT, "tests", "golden", "blosum62.txt"), dst)
+        with pytest.raises(pkg.FailedLookup):                  # the miss above is cached for this directory ...
+            pkg.Matrix.from_name(name)
+        other = name + "b"                                    # ... a name not asked for before is found
+        shutil.copy(dst, os.path.join(shipped, other))
+        m = pkg.Matrix.from_name(other)
+        assert (m.to_numpy() == pkg.Matrix.from_name("blosum62").to_numpy()).all()
+    finally:
+        for f in (dst, os.path.join(shipped, name + "b")):
+            if os.path.exists(f):
+                os.remove(f)
+
+
 def test_environment_switches_are_tabled(pkg):
     """The library reads the environment only through pmx_env(), and only names listed in csrc/pmx_switches.h (which
     tests/test_gpu_switches.py sweeps on the GPU): no stray getenv, no unlisted or unused switch."""
@@ -246,7 +272,7 @@ def test_environment_switches_are_tabled(pkg):
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "parasail-rs_amd", "csrc")
     table = pkg.switches()
     names = {t[0] for t in table}
-    assert len(names) == len(table) and all(t[1] in ("force", "value", "path", "diag") and t[2] for t in table)
+    assert len(names) == len(table) and all(t[1] in ("force", "value", "path", "diag", "convention") and t[2] for t in table)
     used = set()
     for f in glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")):
         src = open(f).read()

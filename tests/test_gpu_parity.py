@@ -804,6 +804,75 @@ def test_batch_cigar_semi_global(pkg, orc):
             assert cig[k] == orc.cigar(w), (mode, k)
 
 
+def test_cigar_letter_convention_is_selectable_at_run_time(pkg, orc, monkeypatch):
+    """The letters of the two gap states are unpinned (include/pmx_conventions.h; the reference's test only prints its CIGAR,
+    tests/test_parasail.rs:606-616).  PMX_CIGAR_SWAP_ID=1 exchanges I and D -- in get_cigar's packed ops and decoded text, in
+    ssw's packed CIGAR and in batch CIGAR text -- without a rebuild; traceback strings and everything else are unchanged."""
+    import re
+    swap = str.maketrans("ID", "DI")
+    bam = "MIDNSHP=X"
+    rng = np.random.default_rng(2602)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 2200, 60, 140)
+    rs = [mutate(rng, q, 0.08, 0.08) for q in qs]
+    for env, tr in ((None, lambda t: t), ("1", lambda t: t.translate(swap)), ("0", lambda t: t)):
+        if env is None:
+            monkeypatch.delenv("PMX_CIGAR_SWAP_ID", raising=False)
+        else:
+            monkeypatch.setenv("PMX_CIGAR_SWAP_ID", env)
+        seen = set()
+        for mode in (1, 0, 2):
+            b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).solution_width(16).use_trace()
+            [b.global_, b.semi_global, b.local][mode]()
+            al = b.build()
+            for n in (40, len(qs)):                                  # the host pipeline of small batches and the device render
+                rec, cig = al.align_batch_cigar(qs[:n], rs[:n])
+                for k in range(0, n, 1 if n == 40 else 37):
+                    w = orc.align(mode, qs[k], rs[k], 5, 2, om, trace=True)
+                    assert cig[k] == tr(orc.cigar(w)), (env, mode, n, k)
+                    seen |= set(re.findall(r"[IDX=]", cig[k]))
+            for k in range(6):                                       # one pair: get_cigar (ops + text) and the traceback strings
+                res = al.align(qs[k], rs[k])
+                w = orc.align(mode, qs[k], rs[k], 5, 2, om, trace=True)
+                assert res.get_cigar(qs[k], rs[k]) == tr(orc.cigar(w))
+                tb = res.get_traceback_strings(qs[k], rs[k])
+                assert (tb.query, tb.comparison, tb.reference) == orc.traceback_strings(w)
+        assert {"I", "D"} <= seen
+        for k in range(20):                                          # ssw: packed ops
+            res = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).build().ssw(qs[k], rs[k])
+            w = orc.align(orc.SW, qs[k], rs[k], 5, 2, om, trace=True)
+            want = [(int(n) << 4) | bam.index(c) for n, c in re.findall(r"(\d+)([=XID])", tr(orc.cigar(w)))]
+            assert [res.cigar()[x] for x in range(res.cigar_len())] == want
+
+
+def test_batch_cigar_text_outlives_every_derived_view(pkg):
+    """The packed CIGAR text is a view of the callee's block; the block must stay alive for DERIVED arrays too (numpy
+    collapses base chains: np.asarray / .view(np.ndarray) / slices drop a subclass attribute), also across a second call
+    that would otherwise be handed the recycled block."""
+    import gc
+    rng = np.random.default_rng(2601)
+    pm = pkg.Matrix.create(b"ACGT", 2, -3)
+    a = pkg.Aligner.new().semi_global().matrix(pm).gap_open(5).gap_extend(2).solution_width(16).use_trace().build()
+    qs = random_seqs(rng, 300, 100, 150)
+    rs = [mutate(rng, q, 0.1, 0.02) for q in qs]
+    qb, qo = pkg.pack(qs)
+    rb, ro = pkg.pack(rs)
+    _, text, coff = a.align_batch_cigar_packed(qb, qo, rb, ro)
+    want = text.tobytes()
+    kept = [np.asarray(text), text.view(np.ndarray), text[3:], np.ascontiguousarray(text)]
+    del text
+    gc.collect()
+    qs2 = random_seqs(rng, 300, 100, 150)                      # another batch of the same size: same pool bucket
+    rs2 = [mutate(rng, q, 0.3, 0.05) for q in qs2]
+    qb2, qo2 = pkg.pack(qs2)
+    rb2, ro2 = pkg.pack(rs2)
+    _, text2, _ = a.align_batch_cigar_packed(qb2, qo2, rb2, ro2)
+    assert text2.tobytes() != want
+    assert kept[0].tobytes() == want and kept[1].tobytes() == want and kept[3].tobytes() == want
+    assert kept[2].tobytes() == want[3:]
+    assert text2.ctypes.data != kept[0].ctypes.data
+
+
 def _stats_case(pkg, orc, mode, sg, qs, rs, open_, ext, pm, om, shared_query=None):
     b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext).solution_width(16)
     [b.global_, b.semi_global, b.local][mode]()

@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 
 # switches whose alternative is only reachable together with another one (the partner is set too)
 PARTNERS = {"PMX_STATS_BY_TRACE_ANY": ["PMX_STATS_BY_TRACE"]}
-VALUES = {"PMX_SW16_VARIANT": ["0", "1", "2"], "PMX_STATS_CHUNK_BYTES": ["3e6"], "PMX_CIGAR_CHUNK_BYTES": ["3e6"]}
-NOT_A_DISPATCH_CHOICE = {"PMX_MATRIX_DIR", "PMX_TIMING"}          # a path (tests/test_abi.py) and a diagnostics print
+VALUES = {"PMX_SW16_VARIANT": ["0", "1", "2"], "PMX_STATS_CHUNK_BYTES": ["3e6"], "PMX_CIGAR_CHUNK_BYTES": ["3e6"],
+          "PMX_TABLE_CHUNK_BYTES": ["1"]}                      # (its batches: tests/test_gpu_tables.py)
+NOT_A_DISPATCH_CHOICE = {"PMX_MATRIX_DIR", "PMX_TIMING", "PMX_CIGAR_SWAP_ID"}          # a path (tests/test_abi.py) and a diagnostics print
 
 
 def _suite(pkg, orc):
@@ -141,7 +142,7 @@ def test_every_switch_is_result_neutral(pkg, orc, monkeypatch):
     names = [t[0] for t in table]
     assert len(set(names)) == len(names)
     for name, kind, what in table:
-        assert name.startswith("PMX_") and kind in ("force", "value", "path", "diag") and what, (name, kind)
+        assert name.startswith("PMX_") and kind in ("force", "value", "path", "diag", "convention") and what, (name, kind)
         monkeypatch.delenv(name, raising=False)
     cases, expect = _suite(pkg, orc)
     base_kernels = {}

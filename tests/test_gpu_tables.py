@@ -69,6 +69,28 @@ def test_table_kernel_protein_1000_by_1000_and_rowcol_only(pkg, orc):
             assert tuple(out[k, :3]) == (w.score, w.end_query, w.end_ref)
 
 
+@pytest.mark.parametrize("chunk_bytes", [None, "1", "71000", "142000"])
+def test_table_batches_beyond_the_table_kernel_in_chunks(pkg, orc, monkeypatch, chunk_bytes):
+    """References beyond the row-by-row kernel's 1 024 columns: the general kernel, in chunks of bounded scratch.  Chunks of
+    one pair (n = k * chunk + 1 leaves one; a forced tiny chunk makes every chunk one pair) keep the packed row / column
+    addressing of the batch (round-2 advisor finding: they used to be rejected)."""
+    rng = np.random.default_rng(9250)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 5, 30, 90)
+    rs = random_seqs(rng, 5, 1030, 1100)
+    if chunk_bytes is not None:
+        monkeypatch.setenv("PMX_TABLE_CHUNK_BYTES", chunk_bytes)      # 1 -> one pair per chunk; 71000 -> two (5 = 2 * 2 + 1); 142000 -> four
+    for mode in (0, 1, 2):
+        cfg = pkg.pmx_config_t(mode, 15, 5, 2, 32, 0, pm.inner)
+        table, row, col, out, toff, qo, ro = _batch_tables(pkg, cfg, qs, rs)
+        assert pkg.lib.pmx_last_kernel().decode() == "pmx_general_kernel/tables"
+        for k in range(len(qs)):
+            w = orc.align(mode, qs[k], rs[k], 5, 2, om, table=True, rowcol=True)
+            assert (table[toff[k]:toff[k + 1]].reshape(len(qs[k]), len(rs[k])) == w.score_table).all(), (mode, k)
+            assert (row[ro[k]:ro[k + 1]] == w.score_row).all() and (col[qo[k]:qo[k + 1]] == w.score_col).all(), (mode, k)
+            assert tuple(out[k, :3]) == (w.score, w.end_query, w.end_ref)
+
+
 def test_single_pair_table_accessors_use_the_table_kernel(pkg, orc):
     """Aligner::use_table / use_last_rowcol (src/aligner/mod.rs:225-246) -> get_score_table / row / col on one pair"""
     rng = np.random.default_rng(9300)
