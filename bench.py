@@ -111,9 +111,10 @@ def cpu_model():
 
 def pmc_summary(config, kernel):
     """Counters of the dominant kernel from the committed PMC passes (profiles/r*/cfg<N>_pmc_summary.json, made by
-    profiles/run_profile.sh + summarize_pmc.py: separate --pmc passes).  Used only when the profiled kernel is the
-    one that just ran; the source file is named in the line.  gfx950 correction (MI355X_MICROARCH.md):
-    FETCH_SIZE counts half of the fetched bytes; both counters are in KiB."""
+    profiles/collect.sh: separate --pmc passes of the serialised pipeline).  Used only when the profiled kernel is the one that
+    just ran AND its source file is byte-for-byte the one the counters were collected on (the summary records the git blob ids;
+    a kernel edit that keeps the name must not report stale counters); the source file is named in the line.  gfx950
+    correction (MI355X_MICROARCH.md): FETCH_SIZE counts half of the fetched bytes; both counters are in KiB."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "cfg%d_pmc_summary.json" % config)))
     if not files:
         return None
@@ -122,6 +123,17 @@ def pmc_summary(config, kernel):
         if d.get("kernel", "") and d["kernel"].split("<")[0] not in kernel:
             return None
         out = {"source": os.path.relpath(files[-1], ROOT), "profiled_kernel": d.get("kernel")}
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from summarize_pmc import source_blobs
+        recorded = d.get("source_blobs")
+        if not recorded:
+            return {"source": out["source"], "stale": "%s records no source blob ids: counters not quoted" % out["source"]}
+        now = source_blobs(d.get("kernel", ""))
+        changed = [f for f in recorded if now.get(f) != recorded[f]]
+        if changed:
+            return {"source": out["source"],
+                    "stale": "%s was collected on another version of %s (blob %s, now %s): counters not quoted"
+                             % (out["source"], changed[0], recorded[changed[0]][:10], str(now.get(changed[0]))[:10])}
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             per_step = float(d.get("launches_per_step", 1.0))       # chunked pipelines launch the sweep several times per step
             out["traffic"] = int((2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024 * per_step)
@@ -132,8 +144,8 @@ def pmc_summary(config, kernel):
                                         "frac": round(d["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] /
                                                       max(1.0, d["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"]), 4)}
         return out
-    except Exception:
-        return None
+    except Exception as e:
+        return {"source": os.path.relpath(files[-1], ROOT), "stale": "unreadable summary (%s)" % e}
 
 
 # ------------------------------------------------------------------------------------------ workloads ----
@@ -380,15 +392,25 @@ class Cfg4(Workload):
                                           wl.CFG4["len"], wl.CFG4["len"], self.d_out[k % 2].data_ptr(),
                                           self.d_text[k % 2].data_ptr(), self.cap, self.d_toff[k % 2].data_ptr(), stream.cuda_stream)
 
-    def exchange(self, k, sharding, backend):
+    def exchange(self, k, sharding, backend, cache=None):
         """N > 1: this step's CIGAR text follows the records to rank 0 (sizes first, then offsets and text padded to the longest
         shard; parasail-rs_amd/sharding.py:gather_text).  Returns the works still in flight."""
         text, toff = self.d_text[k % 2], self.d_toff[k % 2]
         if backend != "nccl":
             text, toff = text.cpu(), toff.cpu()
-        fin, works = sharding.gather_text(text, toff, self.counts, dst=0, async_op=True)
+        fin, works = sharding.gather_text(text, toff, self.counts, dst=0, async_op=True, cache=cache)
         self.last_text_gather = fin
         return works
+
+    def check_exchange(self, last_records):
+        """one-rank rehearsal of the exchange: the gathered records, text and offsets equal the local ones"""
+        k = self.last_k
+        text, toff = self.last_text_gather()
+        n_bytes = int(self.d_toff[k % 2][-1].item())
+        return {"records_equal_local": bool((last_records().cpu() == self.d_out[k % 2].cpu()).all().item()),
+                "text_equal_local": bool((text.cpu() == self.d_text[k % 2][:n_bytes].cpu()).all().item()),
+                "offsets_equal_local": bool((toff.cpu() == self.d_toff[k % 2].cpu()).all().item()),
+                "text_bytes": n_bytes}
 
     def finish(self):
         total = int(self.d_toff[self.last_k % 2][-1].item())
@@ -546,62 +568,28 @@ class Cfg5(Workload):
 WORKLOADS = {2: Cfg2, 3: Cfg3, 4: Cfg4, 5: Cfg5}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
-    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
-    ap.add_argument("--pairs", type=int, default=None, help=argparse.SUPPRESS)
-    ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
-    args = ap.parse_args()
+class _Env:
+    """What every config's run shares: the package, the device, the process group."""
+    pass
 
-    import torch
-    import __graft_entry__ as g
-    pkg = g.load_pkg()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print("bench.py: --gpus %d needs torch.distributed.run with %d processes" % (args.gpus, args.gpus),
-              file=sys.stderr)
-        sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
-        sys.exit(3)
-    # PMX_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share
-    # devices, records are gathered through host memory); the driver's runs use nccl (= RCCL).
-    backend = os.environ.get("PMX_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    # PMX_BENCH_FORCE_DIST=1 (rehearsal on a one-GPU box): take the exchange path with a single rank
-    multi = world > 1 or bool(os.environ.get("PMX_BENCH_FORCE_DIST"))
-    if multi:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend=backend)
-
-    w = WORKLOADS[args.config](pkg, torch, dev, rank, world, args.scaling, args.pairs)
+def run_config(env, config, steps, warmup, scaling, pairs, cpu_legs=True):
+    """One BASELINE config: W untimed + K timed steps bracketed by barrier + synchronize, max over ranks.
+    Returns the JSON line as a dict on rank 0, None elsewhere."""
+    torch, pkg, dev, dist = env.torch, env.pkg, env.dev, env.dist
+    rank, world, multi, backend, sharding = env.rank, env.world, env.multi, env.backend, env.sharding
+    w = WORKLOADS[config](pkg, torch, dev, rank, world, scaling, pairs)
     w.setup()
-    steps = args.steps if args.steps is not None else w.default_steps
-    warmup = args.warmup if args.warmup is not None else w.default_warmup
-
-    from importlib import import_module
-    sharding = import_module("parasail_rs_amd.sharding")
-    comm_stream = torch.cuda.Stream(device=dev) if multi else None
+    steps = steps if steps is not None else w.default_steps
+    warmup = warmup if warmup is not None else w.default_warmup
+    comm_stream = env.comm_stream
     pending = []
+    recv_cache = [{}, {}]             # receive buffers of the exchange step, one set per output slot, allocated once
 
     def step(k, events=None):
         out = w.records(k)
         stream = torch.cuda.current_stream(dev)
-        while len(pending) >= 2:          # the gather that last read this output buffer must be done
+        while len(pending) >= 2:          # the gather that last read this output buffer (and wrote this slot's receive buffers) must be done
             fin, work = pending.pop(0)
             work.wait()
         if events is not None:
@@ -612,17 +600,19 @@ def main():
             events[1].record(stream)
         if multi:
             # exchange step: records of this step go to rank 0 while the next step computes
+            cache = recv_cache[k % 2]
             if backend == "nccl":
                 done = torch.cuda.Event()
                 done.record(stream)
                 with torch.cuda.stream(comm_stream):
                     comm_stream.wait_event(done)
-                    fin, work = sharding.gather_records(out, w.counts, dst=0, async_op=True)
-                    extra = w.exchange(k, sharding, backend) if hasattr(w, "exchange") else []
+                    fin, work = sharding.gather_records(out, w.counts, dst=0, async_op=True, cache=cache)
+                    extra = w.exchange(k, sharding, backend, cache) if hasattr(w, "exchange") else []
             else:
-                fin, work = sharding.gather_records(out.cpu(), w.counts, dst=0, async_op=True)
-                extra = w.exchange(k, sharding, backend) if hasattr(w, "exchange") else []
+                fin, work = sharding.gather_records(out.cpu(), w.counts, dst=0, async_op=True, cache=cache)
+                extra = w.exchange(k, sharding, backend, cache) if hasattr(w, "exchange") else []
             pending.append((fin, _Works([work] + list(extra))))
+            env.last_gather = fin
 
     def drain():
         while pending:
@@ -662,40 +652,125 @@ def main():
     if hasattr(w, "finish"):
         w.finish()
 
+    line = None
     if rank == 0:
         gcups = cells_all * steps / elapsed / 1e9
         achieved = w.algo_bytes / (kern_ms * 1e-3) / 1e9
         kern_gcups = w.cells / (kern_ms * 1e-3) / 1e9
-        pmc = pmc_summary(args.config, kernel) if args.pairs is None and args.scaling == "weak" else None
+        pmc = pmc_summary(config, kernel) if pairs is None and scaling == "weak" else None
         line = {
             "metric": w.metric, "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": w.dtype, "data": "synthetic",
             "value_is": "device-resident batch throughput (inputs already in HBM when the timed region starts, the bench contract's "
                         "definition); SURVEY.md 8(d)'s end-to-end form (H2D + kernels + D2H through the host entry) is `pcie_inclusive`",
             "config": {"workload": w.workload, "pairs_per_gpu": w.n, "kernel": kernel, "inputs": "resident in HBM",
-                       "exchange": "none" if world == 1 else "%s gather of 16-B records%s to rank 0, overlapped" %
+                       "exchange": "none" if not multi else "%s gather of 16-B records%s to rank 0, overlapped" %
                                    ("RCCL" if backend == "nccl" else backend, " and of the CIGAR text" if hasattr(w, "exchange") else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc.get("traffic") if pmc else None,
                          "traffic_source": pmc.get("source") if pmc else None,
+                         "traffic_over_algorithmic": round(pmc["traffic"] / w.algo_bytes, 2) if pmc and pmc.get("traffic") else None,
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": int(w.algo_bytes),
                          "note": w.algo_note + "; the path is VALU-bound, see roofline_valu"},
         }
         if pmc and "lds_bank_conflict" in pmc:
             line["lds_bank_conflict"] = dict(pmc["lds_bank_conflict"], source=pmc["source"])
+        if pmc and pmc.get("stale"):
+            line["roofline"]["traffic_note"] = pmc["stale"]
         peak, model = valu_ceiling(kernel)
         if peak:
             line["roofline_valu"] = {"bound": "valu", "achieved": round(kern_gcups, 2), "peak": round(peak, 1), "unit": "GCUPS",
                                      "frac": round(kern_gcups / peak, 4), "model": model}
-        if world == 1 and not multi and args.pairs is None and not args.no_cpu_baseline and hasattr(w, "pcie_inclusive"):
+        if multi and world == 1:
+            # rehearsal of the exchange path with one rank (PMX_BENCH_FORCE_DIST): what rank 0 gathered must be what it computed
+            line["exchange_check"] = w.check_exchange(env.last_gather) if hasattr(w, "check_exchange") else \
+                {"records_equal_local": bool((env.last_gather().cpu() == w.records(w.last_k).cpu()).all().item())}
+        if world == 1 and not multi and pairs is None and cpu_legs and hasattr(w, "pcie_inclusive"):
             # the same batch handed over in host memory (H2D + kernels + D2H inside): reported beside, never as `value`
             line["pcie_inclusive"] = w.pcie_inclusive()
         if world == 1 and not multi and hasattr(w, "extra"):
             line.update(w.extra())
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and cpu_legs:
             last_out = w.records(w.last_k).cpu().numpy()
             line["cpu_baseline"] = w.cpu_baseline(last_out)
+    del w
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return line
+
+
+# steps / warm-up of the configs that ride along with the default (headline) run: sized so that the whole default run --
+# input generation included -- stays within a couple of minutes
+ALONGSIDE = {3: (5, 1), 4: (10, 2), 5: (3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=None, choices=sorted(WORKLOADS),
+                    help="one config only (default: config 2 as the line's value, and at one GPU configs 3, 4, 5 beside it under \"configs\")")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--pairs", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--headline-only", action="store_true", help="default run without configs 3-5")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as g
+    pkg = g.load_pkg()
+
+    env = _Env()
+    env.torch, env.pkg = torch, pkg
+    env.rank = rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    env.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print("bench.py: --gpus %d needs torch.distributed.run with %d processes" % (args.gpus, args.gpus),
+              file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    # PMX_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share
+    # devices, records are gathered through host memory); the driver's runs use nccl (= RCCL).
+    env.backend = backend = os.environ.get("PMX_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    env.dev = dev = torch.device("cuda", dev_index)
+    env.dist = dist = None
+    # PMX_BENCH_FORCE_DIST=1 (rehearsal on a one-GPU box): take the exchange path with a single rank
+    env.multi = multi = world > 1 or bool(os.environ.get("PMX_BENCH_FORCE_DIST"))
+    if multi:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+        env.dist = dist
+    from importlib import import_module
+    env.sharding = import_module("parasail_rs_amd.sharding")
+    env.comm_stream = torch.cuda.Stream(device=dev) if multi else None
+    env.last_gather = None
+
+    head = args.config if args.config is not None else 2
+    line = run_config(env, head, args.steps, args.warmup, args.scaling, args.pairs, cpu_legs=not args.no_cpu_baseline)
+    if (args.config is None and not args.headline_only and world == 1 and not multi and args.pairs is None
+            and args.scaling == "weak"):
+        # the other BASELINE configs under the same clock (each: value, ms_per_step, roofline, roofline_valu, cpu_baseline, pcie_inclusive)
+        line["configs"] = {}
+        for c in sorted(ALONGSIDE):
+            t0 = time.perf_counter()
+            sub = run_config(env, c, ALONGSIDE[c][0], ALONGSIDE[c][1], "weak", None, cpu_legs=not args.no_cpu_baseline)
+            for key in ("higher_is_better", "vs_baseline", "data", "value_is", "n_gpus", "scaling"):
+                sub.pop(key, None)
+            sub["wall_s_incl_input_generation"] = round(time.perf_counter() - t0, 1)
+            line["configs"][str(c)] = sub
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

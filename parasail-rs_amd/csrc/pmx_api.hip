@@ -1279,7 +1279,9 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
     size_t cbytes = 0;
     (void)pmx_nwsgq_trace_plan(bc, dm.d, cfg->mode, cfg->open, cfg->extend, &variant, &Tmax, &cbytes, &G, &R);
     cbytes = (cbytes + 255) & ~(size_t)255;
-    const bool two = chunk < b.n;
+    // (PMX_STATS_NO_OVERLAP: sweep and walk of every chunk back to back on the caller's stream, one trace buffer -- the form the
+    //  serialised kernel traces under profiles/ are taken in: per-launch durations of overlapping launches cannot be added up)
+    const bool two = chunk < b.n && !pmx_env("PMX_STATS_NO_OVERLAP");
     uint32_t *tbuf = nullptr;
     if (scratch_reserve(cbytes * (two ? 2 : 1), (void **)&tbuf, SCR_TRACE)) return -1;
     const bool sg = cfg->mode == PMX_MODE_SG;

@@ -30,11 +30,31 @@ def shard_bounds_by_cells(qlens, rlens, world):
     return bounds
 
 
-def gather_records(local, counts, dst=0, group=None, async_op=False):
+def _recv_buffers(cache, key, like, world, rows=None):
+    """`world` receive tensors of `rows` rows (default: all of `like`'s) with `like`'s trailing shape, dtype and device.  With a
+    cache (a dict the caller keeps, e.g. one per double-buffer slot) they are views of tensors allocated ONCE at `like`'s full
+    size and reused from step to step: a step of the 8-GPU cfg-4 exchange would otherwise take 8 x 20 MB from the allocator
+    on the communication stream every time."""
+    import torch
+    need = like.shape[0] if rows is None else rows
+    tail = tuple(like.shape[1:])
+    if cache is None:
+        return [torch.empty((need,) + tail, dtype=like.dtype, device=like.device) for _ in range(world)]
+    have = cache.get(key)
+    if (have is None or len(have) != world or have[0].shape[0] < need or tuple(have[0].shape[1:]) != tail
+            or have[0].dtype != like.dtype or have[0].device != like.device):
+        cap = max(need, like.shape[0])
+        have = [torch.empty((cap,) + tail, dtype=like.dtype, device=like.device) for _ in range(world)]
+        cache[key] = have
+    return [b[:need] for b in have]
+
+
+def gather_records(local, counts, dst=0, group=None, async_op=False, cache=None):
     """Gather per-rank record tensors ([n_g, 4] int32) to `dst` in rank order.
 
     counts[g] = rows held by rank g (known to every rank from the shard plan).  Equal counts use
-    a single gather; ragged counts are padded to the maximum.  Returns (tensor_or_None, work)."""
+    a single gather; ragged counts are padded to the maximum.  `cache`: see _recv_buffers (the caller must not reuse a
+    cache while a gather into it is still in flight).  Returns (tensor_or_None, work)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -44,7 +64,7 @@ def gather_records(local, counts, dst=0, group=None, async_op=False):
     if local.shape[0] != mx:
         send = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         send[: local.shape[0]] = local
-    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    bufs = _recv_buffers(cache, "records", send, world) if rank == dst else None
     work = dist.gather(send, bufs, dst=dst, group=group, async_op=async_op)
 
     def finish():
@@ -56,7 +76,7 @@ def gather_records(local, counts, dst=0, group=None, async_op=False):
     return finish(), None
 
 
-def gather_text(text, toff, counts, dst=0, group=None, async_op=False):
+def gather_text(text, toff, counts, dst=0, group=None, async_op=False, cache=None):
     """Gather packed CIGAR text (the device-entry layout: one uint8 buffer + int64 offsets[n_g + 1] per rank) to `dst`.
 
     Two phases, like gather_strings: every rank learns every rank's byte count (one tiny all_gather + one host read, the
@@ -76,8 +96,9 @@ def gather_text(text, toff, counts, dst=0, group=None, async_op=False):
     body = text[:mx_b] if text.shape[0] >= mx_b else torch.cat([text, text.new_zeros(mx_b - text.shape[0])])
     offs = toff[:mx_n] if toff.shape[0] >= mx_n else torch.cat([toff, toff.new_zeros(mx_n - toff.shape[0])])
     body, offs = body.contiguous(), offs.contiguous()
-    body_all = [torch.empty_like(body) for _ in range(world)] if rank == dst else None
-    offs_all = [torch.empty_like(offs) for _ in range(world)] if rank == dst else None
+    # (receive buffers from the caller's cache, sized once for the sender's whole text capacity: the bytes differ per step)
+    body_all = _recv_buffers(cache, "text", text if text.shape[0] >= mx_b else body, world, rows=mx_b) if rank == dst else None
+    offs_all = _recv_buffers(cache, "text_off", offs, world) if rank == dst else None
     works = [dist.gather(offs, offs_all, dst=dst, group=group, async_op=async_op),
              dist.gather(body, body_all, dst=dst, group=group, async_op=async_op)]
 

@@ -25,9 +25,10 @@ def _seq(buf, off, k):
 
 
 def test_cfg3_shared_profile_nw_stats_full_shape(pkg, orc):
-    """cfg 3: one 300-aa query (reused stats profile) against 12 500 references of 4.5-5 kaa (one GPU's share of the
-    100k), `nw_stats_striped_profile_16`, BLOSUM62 11/1: 256 sampled pairs against the oracle with statistics."""
-    n = wl.CFG3["n"] // 8
+    """cfg 3 at its FULL size (it is a one-GPU config): one 300-aa query (reused stats profile) against all 100 000 references
+    of 4.5-5 kaa, `nw_stats_striped_profile_16`, BLOSUM62 11/1 -- the several-chunk pipeline of the statistics-by-traceback
+    route as bench.py runs it; 256 sampled pairs against the oracle with statistics, every pair through the properties."""
+    n = wl.CFG3["n"]
     q, rbuf, roff = wl.make_cfg3(n)
     pm = pkg.Matrix.from_name("blosum62")
     om = orc.Matrix.from_file(os.path.join(ROOT, "tests", "golden", "blosum62.txt"))
@@ -61,15 +62,17 @@ def test_cfg3_shared_profile_nw_stats_full_shape(pkg, orc):
     # on every pair of the first 2 000 references, as does the traceback route forced into many small chunks
     m = 2000
     import os as _os
-    for env, val in (("PMX_NO_STATS_BY_TRACE", "1"), ("PMX_STATS_CHUNK_BYTES", "300e6")):
-        _os.environ[env] = val
+    for envs in ({"PMX_NO_STATS_BY_TRACE": "1"}, {"PMX_STATS_CHUNK_BYTES": "300e6"},
+                 {"PMX_STATS_CHUNK_BYTES": "300e6", "PMX_STATS_NO_OVERLAP": "1"}):       # (the serialised form of the profiles)
+        _os.environ.update(envs)
         try:
             rec2, st2 = al.align_batch_packed(None, None, rbuf[:roff[m]], roff[:m + 1])
             k2 = pkg.lib.pmx_last_kernel().decode()
         finally:
-            del _os.environ[env]
-        assert ("stats16p" in k2) == (env == "PMX_NO_STATS_BY_TRACE"), k2
-        assert (rec2 == rec[:m]).all() and (st2 == st[:m]).all(), env
+            for env in envs:
+                del _os.environ[env]
+        assert ("stats16p" in k2) == ("PMX_NO_STATS_BY_TRACE" in envs), k2
+        assert (rec2 == rec[:m]).all() and (st2 == st[:m]).all(), envs
 
 
 def test_cfg3_one_off_form_matrix_lookup(pkg, orc):
@@ -199,6 +202,30 @@ def test_two_ranks_share_one_gpu_hip_path(pkg, orc):
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "dist gpu ok world=2" in p.stdout
+
+
+@pytest.mark.parametrize("config,pairs", [(2, 40000), (4, 20000)])
+def test_rccl_exchange_path_with_one_rank(config, pairs):
+    """The `nccl` (= RCCL) branch of bench.py -- init_process_group("nccl"), the records' gather on the communication stream with
+    cached receive buffers, for config 4 the two-phase gather of the CIGAR text -- executed on the GPU box with ONE rank, in a
+    fresh child process that initialises the process group before any other GPU call (the first 8-GPU run must not be this
+    code's first run).  The child checks that what rank 0 gathered equals what it computed."""
+    import json
+    env = dict(os.environ, PMX_BENCH_FORCE_DIST="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29540 + config), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PMX_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(config), "--pairs", str(pairs), "--steps", "4",
+           "--warmup", "2", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["exchange"].startswith("RCCL gather"), line["config"]
+    assert line["config"]["pairs_per_gpu"] == pairs and line["steps"] == 4
+    chk = line["exchange_check"]
+    assert chk["records_equal_local"] is True, chk
+    if config == 4:
+        assert "CIGAR text" in line["config"]["exchange"]
+        assert chk["text_equal_local"] is True and chk["offsets_equal_local"] is True and chk["text_bytes"] > pairs * 5, chk
 
 
 def test_cigar_device_entry_and_capacity(pkg, orc):
