@@ -1183,7 +1183,7 @@ static int general_batch(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
     const bool fits = pmx_general_lds_fits(dm.d.msize, dm.d.msize, max_rlen);
     const size_t rs_stride = fits ? 0 : (((size_t)max_rlen + 8 + 15) & ~(size_t)15);
     const size_t per_pair = stride * sizeof(int32_t) + rs_stride;
-    const char *cb = pmx_env("PMX_TABLE_CHUNK_BYTES");
+    const char *cb = pmx_env("PMX_GENERAL_CHUNK_BYTES");
     int64_t chunk = (int64_t)((cb && atof(cb) > 0 ? atof(cb) : 2e9) / (double)per_pair);
     if (chunk < 1) chunk = 1;
     if (chunk > n) chunk = n;
@@ -1921,7 +1921,7 @@ extern "C" int pmx_align_batch_table_device(const pmx_config_t *cfg, int64_t n,
     const bool fits = pmx_general_lds_fits(dm.d.msize, dm.d.msize, max_rlen);
     const size_t rs_stride = fits ? 0 : (((size_t)max_rlen + 8 + 15) & ~(size_t)15);
     const size_t per_pair = stride * sizeof(int32_t) + rs_stride;
-    const char *cb = pmx_env("PMX_TABLE_CHUNK_BYTES");
+    const char *cb = pmx_env("PMX_GENERAL_CHUNK_BYTES");
     int64_t chunk = (int64_t)((cb && atof(cb) > 0 ? atof(cb) : 2e9) / (double)per_pair);
     if (chunk < 1) chunk = 1;
     if (chunk > n) chunk = n;

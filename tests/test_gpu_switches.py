@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 # switches whose alternative is only reachable together with another one (the partner is set too)
 PARTNERS = {"PMX_STATS_BY_TRACE_ANY": ["PMX_STATS_BY_TRACE"]}
 VALUES = {"PMX_SW16_VARIANT": ["0", "1", "2"], "PMX_STATS_CHUNK_BYTES": ["3e6"], "PMX_CIGAR_CHUNK_BYTES": ["3e6"],
-          "PMX_TABLE_CHUNK_BYTES": ["1"]}                      # (its batches: tests/test_gpu_tables.py)
+          "PMX_GENERAL_CHUNK_BYTES": ["1"]}                      # (its batches: tests/test_gpu_tables.py)
 NOT_A_DISPATCH_CHOICE = {"PMX_MATRIX_DIR", "PMX_TIMING", "PMX_CIGAR_SWAP_ID"}          # a path (tests/test_abi.py) and a diagnostics print
 
 

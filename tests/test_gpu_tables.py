@@ -79,7 +79,7 @@ def test_table_batches_beyond_the_table_kernel_in_chunks(pkg, orc, monkeypatch, 
     qs = random_seqs(rng, 5, 30, 90)
     rs = random_seqs(rng, 5, 1030, 1100)
     if chunk_bytes is not None:
-        monkeypatch.setenv("PMX_TABLE_CHUNK_BYTES", chunk_bytes)      # 1 -> one pair per chunk; 71000 -> two (5 = 2 * 2 + 1); 142000 -> four
+        monkeypatch.setenv("PMX_GENERAL_CHUNK_BYTES", chunk_bytes)      # 1 -> one pair per chunk; 71000 -> two (5 = 2 * 2 + 1); 142000 -> four
     for mode in (0, 1, 2):
         cfg = pkg.pmx_config_t(mode, 15, 5, 2, 32, 0, pm.inner)
         table, row, col, out, toff, qo, ro = _batch_tables(pkg, cfg, qs, rs)
