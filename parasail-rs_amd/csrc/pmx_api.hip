@@ -1146,7 +1146,8 @@ enum { SCR_BOUND = 0, SCR_TRACE = 1, SCR_OPS = 2, SCR_SORT = 3, SCR_RETRY = 4,
        SCR_CIG = 11,                                                                     // device CIGAR entry: counts, begins, text lengths, scan scratch
        SCR_HTEXT = 12, SCR_HTOFF = 13,                                                   // staging of the host CIGAR entry
        SCR_HQ2 = 14, SCR_HR2 = 15,                                                       // 2-bit packed input as it arrived
-       SCR_SLOTS = 16 };
+       SCR_LONG = 16,                                                                    // boundary granules + band candidates of pmx_long.hip
+       SCR_SLOTS = 17 };
 static thread_local Scratch g_scratch_pool[SCR_SLOTS];
 static int scratch_reserve(size_t bytes, void **out, int slot = SCR_BOUND)
 {
@@ -1344,6 +1345,34 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         if (scratch_reserve(pmx_sort_scratch_bytes(n), &scr, SCR_SORT)) return -1;
         const int rc = pmx_build_length_perm(d_roff, n, scr, &b.perm, st);
         if (rc < 0) { set_err("length sort failed (%d)", rc); return rc; }
+    }
+    // Few long pairs (one align() call on kilobases: src/aligner/mod.rs:397-430 has no length limit): the query's bands spread
+    // over the chip (pmx_long.hip).  Widths: local -- any (saturation = a score beyond the width); global / semi-global -- sat, 32,
+    // 64, or a fixed width whose range the boundary row / column already leaves (one pair: its lengths are known here).
+    if (want == 0 && n <= 16 && !b.perm && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && max_qlen >= 512 &&
+        (long long)max_qlen * max_rlen >= (3LL << 20) && !pmx_env("PMX_NO_LONG_KERNEL")) {
+        bool ok = true; int force_sat = 0, sat_above = 2147483647;
+        const int wmax = cfg->width == 8 ? 127 : cfg->width == 16 ? 32767 : 2147483647;
+        if (cfg->mode == PMX_MODE_SW) sat_above = wmax;
+        else if (cfg->width == 8 || cfg->width == 16) {
+            const bool pen_col = cfg->mode == PMX_MODE_NW || !(cfg->sg_flags & PMX_SG_QB), pen_row = cfg->mode == PMX_MODE_NW || !(cfg->sg_flags & PMX_SG_DB);
+            const long long lo = std::min(pen_col ? -((long long)cfg->open + (long long)(max_qlen - 1) * cfg->extend) : 0LL,
+                                          pen_row ? -((long long)cfg->open + (long long)(max_rlen - 1) * cfg->extend) : 0LL);
+            if (n == 1 && lo < -(long long)wmax - 1) force_sat = 1; else ok = false;     // (inside the range: the general kernel tracks min / max H)
+        }
+        if (ok) {
+            int R = 4; long long bstride = 0; int nbmax = 0;
+            size_t bytes = pmx_long_scratch_bytes(n, max_qlen, max_rlen, R, &bstride, &nbmax);
+            if (bytes > ((size_t)4 << 30)) { R = 16; bytes = pmx_long_scratch_bytes(n, max_qlen, max_rlen, R, &bstride, &nbmax); }
+            size_t fb = 0, tb = 0;
+            if (hipMemGetInfo(&fb, &tb) != hipSuccess) fb = 0;
+            void *scr = nullptr;
+            if (bytes <= fb / 4 + ((size_t)64 << 20) && scratch_reserve(bytes, &scr, SCR_LONG) == 0) {
+                const int rc = pmx_launch_long(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, R, scr, d_out, sat_above, force_sat, st);
+                if (rc < 0) { set_err("long-pair kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
+                if (rc == 0) { g_last_kernel = R == 4 ? "pmx_long32_kernel<4>/bands across the chip" : "pmx_long32_kernel<16>/bands across the chip"; return 0; }
+            }
+        }
     }
     if (fast_sw_eligible(cfg)) {
         b.q_has_wildcard = q_shared ? q_shared_wild : 0;

@@ -268,13 +268,18 @@ def test_long_single_pairs_share_the_waves_of_a_workgroup(pkg, orc, mode):
     rs = [mutate(rng, q, 0.1, 0.03) if k % 2 == 0 else random_seqs(rng, 1, 700, 3000)[0] for k, q in enumerate(qs)]
     qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
     want = orc.align_stats_sample(mode, np.arange(len(qs)), qb, qo, rb, ro, 5, 2, om)
-    got = al.align_batch(qs, rs)
-    assert pkg.lib.pmx_last_kernel().decode() == "pmx_general_kernel"
+    import os
+    os.environ["PMX_NO_LONG_KERNEL"] = "1"                         # (score-only calls of this size now take pmx_long32_kernel: tests/test_gpu_long.py)
+    try:
+        got = al.align_batch(qs, rs)
+        assert pkg.lib.pmx_last_kernel().decode() == "pmx_general_kernel"
+        one = al.align(qs[0], rs[0])
+    finally:
+        del os.environ["PMX_NO_LONG_KERNEL"]
     assert (got["score"] == want[:, 0]).all() and (got["end_query"] == want[:, 1]).all() and (got["end_ref"] == want[:, 2]).all()
     rec, st = als.align_batch(qs, rs)
     assert (rec["score"] == want[:, 0]).all() and (st["matches"] == want[:, 3]).all() and (st["similar"] == want[:, 4]).all() \
         and (st["length"] == want[:, 5]).all()
-    one = al.align(qs[0], rs[0])
     assert (one.get_score(), one.get_end_query(), one.get_end_ref()) == tuple(want[0, :3])
     many_q, many_r = qs[:2] * 40, rs[:2] * 40                      # 80 pairs: one wave per pair
     big = al.align_batch(many_q, many_r)

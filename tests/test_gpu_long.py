@@ -1,0 +1,141 @@
+"""One long pair across the chip (`-m gpu`): pmx_long32_kernel (parasail-rs_amd/csrc/pmx_long.hip).
+
+`Aligner::align()` has no length limit (/root/reference/src/aligner/mod.rs:397-430; :454-456 "for aligning large sequences").
+A call (or a handful of pairs) of >= 512 query rows and >= 3 M cells spreads the query's 256-row bands over the CUs, each band one
+wave, chained through 8-byte granules in HBM.  Everything here is compared with the scalar oracle: every mode and free-end
+variant, lengths around the 64-column chunks and the 256-row bands, tie-heavy inputs for the end-position rules, ragged
+batches, the profile arm, fixed-width saturation, and 20 kbp x 20 kbp."""
+import os
+
+import numpy as np
+import pytest
+
+from util import random_seqs, mutate, DNA, AA
+
+pytestmark = pytest.mark.gpu
+
+LONG = "pmx_long32_kernel"
+
+
+def _rec(a):
+    return np.stack([a["score"], a["end_query"], a["end_ref"]], axis=1)
+
+
+def _builder(pkg, pm, o, e, mode, width=None):
+    b = pkg.Aligner.new().matrix(pm).gap_open(o).gap_extend(e)
+    [b.global_, b.semi_global, b.local][mode]()
+    if width is not None:
+        b.solution_width(width)
+    return b
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("gaps", [(5, 2), (0, 0), (1, 1), (7, 0)])
+def test_ragged_batches_around_chunk_and_band_edges(pkg, orc, mode, gaps):
+    rng = np.random.default_rng(9900 + mode * 10 + gaps[0])
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qlens = [3000, 512, 513, 255, 256, 257, 1, 700, 1024, 1025, 2049, 100, 1279, 1280, 1281, 40]
+    rlens = [3100, 63, 64, 65, 127, 128, 129, 191, 192, 193, 1, 2, 6000, 640, 1000, 5000]
+    qs = [random_seqs(rng, 1, L, L)[0] for L in qlens]
+    rs = []
+    for k, (q, L) in enumerate(zip(qs, rlens)):
+        base = mutate(rng, q, 0.08, 0.04) if k % 2 == 0 else random_seqs(rng, 1, L, L)[0]
+        r = (base + random_seqs(rng, 1, L, L)[0])[:L]
+        rs.append(r)
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    for sg in ((15,) if mode != 1 else (15, 1, 2, 4, 8, 1 | 8, 2 | 4, 3, 12, 5, 10)):
+        b = _builder(pkg, pm, gaps[0], gaps[1], mode)
+        if mode == 1:
+            b.allow_query_gaps([n for f, n in ((1, "prefix"), (2, "suffix")) if sg & f]).allow_ref_gaps([n for f, n in ((4, "prefix"), (8, "suffix")) if sg & f])
+        got = _rec(b.build().align_batch(qs, rs))
+        assert LONG in pkg.lib.pmx_last_kernel().decode(), pkg.lib.pmx_last_kernel()
+        want = orc.align_batch(mode, qb, qo, rb, ro, gaps[0], gaps[1], om, sg_flags=sg)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, (mode, sg, gaps, bad, [(qlens[k], rlens[k]) for k in bad[:4]], got[bad[:4]], want[bad[:4]])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_end_positions_under_ties(pkg, orc, mode):
+    """periodic sequences: the maximum occurs in many cells, several of them in different bands and lanes"""
+    rng = np.random.default_rng(9950 + mode)
+    pm, om = pkg.Matrix.create(b"ACGT", 1, -1), orc.Matrix.create("ACGT", 1, -1)
+    unit = random_seqs(rng, 1, 37, 37)[0]
+    qs = [(unit * 100)[:L] for L in (2000, 1500, 3000, 777)]
+    rs = [(unit * 100)[:L] if k % 2 == 0 else (unit[5:] + unit * 100)[:L] for k, L in enumerate((1800, 2100, 2999, 3500))]
+    qs += [b"A" * 1200, b"ACGT" * 400]; rs += [b"A" * 2600, b"ACGT" * 700]
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    for o, e in ((0, 0), (1, 1), (3, 1)):
+        got = _rec(_builder(pkg, pm, o, e, mode).build().align_batch(qs, rs))
+        assert LONG in pkg.lib.pmx_last_kernel().decode()
+        want = orc.align_batch(mode, qb, qo, rb, ro, o, e, om)
+        assert (got == want).all(), (mode, o, e, got, want)
+
+
+def test_protein_and_profile_arm(pkg, orc):
+    rng = np.random.default_rng(9960)
+    pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    q = random_seqs(rng, 1, 1500, 1500, AA)[0]
+    rs = [mutate(rng, q, 0.3, 0.05, AA), random_seqs(rng, 1, 2500, 2500, AA)[0], (random_seqs(rng, 1, 900, 900, AA)[0] + mutate(rng, q[300:900], 0.2, 0.04, AA))]
+    rb, ro = orc.pack(rs)
+    qb = np.tile(np.frombuffer(q, dtype=np.uint8), len(rs)); qo = np.arange(len(rs) + 1, dtype=np.int64) * len(q)
+    for mode in (0, 1, 2):
+        want = orc.align_batch(mode, qb, qo, rb, ro, 11, 1, om)
+        got = _rec(_builder(pkg, pm, 11, 1, mode).build().align_batch([q] * len(rs), rs))
+        assert LONG in pkg.lib.pmx_last_kernel().decode()
+        assert (got == want).all(), (mode, got, want)
+        prof = pkg.Profile.new(q, False, pm)
+        gotp = _rec(_builder(pkg, pm, 11, 1, mode).profile(prof).build().align_batch([], rs))      # one shared query (profile arm)
+        assert LONG in pkg.lib.pmx_last_kernel().decode()
+        assert (gotp == want).all(), (mode, gotp, want)
+        one = _builder(pkg, pm, 11, 1, mode).profile(prof).build().align(None, rs[1])                # Aligner::align(None, reference)
+        assert (one.get_score(), one.get_end_query(), one.get_end_ref()) == tuple(want[1])
+
+
+def test_fixed_widths_and_saturation(pkg, orc):
+    rng = np.random.default_rng(9970)
+    pm, om = pkg.Matrix.create(b"ACGT", 40, -40), orc.Matrix.create("ACGT", 40, -40)
+    q = random_seqs(rng, 1, 2000, 2000)[0]; r = mutate(rng, q, 0.02, 0.01)
+    for mode in (0, 1, 2):
+        for width in (None, 8, 16, 32, 64):
+            res = _builder(pkg, pm, 50, 5, mode, width).build().align(q, r)
+            w = orc.align(mode, q, r, 50, 5, om, bits=width or 0)
+            if width in (None, 32, 64) or not w.saturated:
+                assert (res.get_score(), res.get_end_query(), res.get_end_ref()) == (w.score, w.end_query, w.end_ref), (mode, width)
+            assert bool(res.is_saturated()) == bool(w.saturated), (mode, width)
+            if width in (None, 32, 64):
+                assert w.score > 32767 and LONG in pkg.lib.pmx_last_kernel().decode()
+    # global, width 16, boundaries inside the range (short gaps): the general kernel tracks the range; results agree anyway
+    pm2, om2 = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    q = random_seqs(rng, 1, 2200, 2200)[0]; r = mutate(rng, q, 0.05, 0.02)
+    res = _builder(pkg, pm2, 5, 2, 0, 16).build().align(q, r)
+    w = orc.align(0, q, r, 5, 2, om2, bits=16)
+    assert (res.get_score(), bool(res.is_saturated())) == (w.score, bool(w.saturated))
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_20_kbp_pair(pkg, orc, mode):
+    rng = np.random.default_rng(9980 + mode)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    q = random_seqs(rng, 1, 20000, 20000)[0]; r = mutate(rng, q, 0.08, 0.03)
+    res = _builder(pkg, pm, 5, 2, mode).build().align(q, r)
+    assert LONG in pkg.lib.pmx_last_kernel().decode()
+    w = orc.align(mode, q, r, 5, 2, om)
+    assert (res.get_score(), res.get_end_query(), res.get_end_ref()) == (w.score, w.end_query, w.end_ref)
+    assert abs(w.score) > 20000
+
+
+def test_short_query_against_a_very_long_reference_and_the_switch(pkg, orc, monkeypatch):
+    rng = np.random.default_rng(9990)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    q = random_seqs(rng, 1, 600, 600)[0]
+    r = random_seqs(rng, 1, 150000, 150000)[0][:70000] + mutate(rng, q, 0.05, 0.02) + random_seqs(rng, 1, 80000, 80000)[0]
+    for mode in (1, 2):
+        res = _builder(pkg, pm, 5, 2, mode).build().align(q, r)
+        assert LONG in pkg.lib.pmx_last_kernel().decode()
+        w = orc.align(mode, q, r, 5, 2, om)
+        assert (res.get_score(), res.get_end_query(), res.get_end_ref()) == (w.score, w.end_query, w.end_ref)
+        monkeypatch.setenv("PMX_NO_LONG_KERNEL", "1")
+        res2 = _builder(pkg, pm, 5, 2, mode).build().align(q, r)
+        assert LONG not in pkg.lib.pmx_last_kernel().decode()
+        monkeypatch.delenv("PMX_NO_LONG_KERNEL")
+        assert (res2.get_score(), res2.get_end_query(), res2.get_end_ref()) == (w.score, w.end_query, w.end_ref)
