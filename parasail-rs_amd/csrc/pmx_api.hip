@@ -1128,7 +1128,7 @@ extern "C" const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen,
     if (check_cfg(cfg)) return "invalid";
     if (fast_sw_eligible(cfg) && cfg->matrix->size <= PMX_MAX_FAST_MSIZE && max_qlen <= 2048 && max_rlen <= 60000)
         return "pmx_sw16_kernel";
-    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && (cfg->want & ~PMX_WANT_SORTED) == 0 && cfg->width != 8 &&
+    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && (cfg->want & ~PMX_WANT_SORTED) == 0 &&
         cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && cfg->open >= cfg->extend && max_qlen <= 2048 &&
         cfg->matrix->size < PMX_MAX_FAST_MSIZE)
         return "pmx_nwsg16_kernel";
@@ -1500,8 +1500,11 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         if (rc < 0) { set_err("stats16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
         if (rc == 0) return 0;
     }
-    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && want == 0 && cfg->width != 8 &&
+    if ((cfg->mode == PMX_MODE_NW || cfg->mode == PMX_MODE_SG) && want == 0 && (cfg->width != 8 || !pmx_env("PMX_NWSG8_GENERAL")) &&
         cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE) {
+        // (width 8: the same int16 kernels, which then also track the range of H for the saturation flag -- the reference's
+        //  narrowest width is its fastest on a CPU; it must not be the slow road here)
+        b.track8 = cfg->width == 8;
         const int rc = pmx_launch_nwsg16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, st, &g_last_kernel);
         if (rc < 0) { set_err("nwsg16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
         if (rc == 0) return 0;     // the host-side range proof makes overflow impossible: no promotion pass

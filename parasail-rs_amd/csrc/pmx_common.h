@@ -31,6 +31,7 @@ struct PmxBatch {
     int q_has_wildcard;      // shared query only: it holds a letter beyond the first four of the alphabet
     int sat_above;           // sw16 only, 0 = off: scores above this set PMX_FLAG_SATURATED (width 8: 127; local H >= 0, so the
                              //   maximum H is the score and the oracle's saturation rule needs nothing else)
+    int track8;              // nwsg16v only: width 8 -- track the range of H and flag pairs that leave [-128, 127]
 };
 #define PMX_FLAG_RETRY16 4   // internal record flag: redo with the LDS-profile variant of the fast kernel
 

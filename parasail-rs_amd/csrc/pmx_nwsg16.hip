@@ -62,6 +62,12 @@ __device__ __forceinline__ v2s n_max3f(v2s a, v2s b, v2s c)     // same instruct
                                                   __builtin_bit_cast(n_v2h, c));
     return __builtin_bit_cast(v2s, r);
 }
+__device__ __forceinline__ v2s n_min3f(v2s a, v2s b, v2s c)     // v_pk_minimum3_f16: exact integer min3 on the same patterns
+{
+    const n_v2h r = __builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_bit_cast(n_v2h, a), __builtin_bit_cast(n_v2h, b)),
+                                                  __builtin_bit_cast(n_v2h, c));
+    return __builtin_bit_cast(v2s, r);
+}
 __device__ __forceinline__ int n_bfi(int m, int a, int b)
 {
     int r;
@@ -405,7 +411,8 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
                         int msize, int open, int ext, int RP, int q_shared,
                         int col_pen, int row_pen, int s1_end, int s2_end, int nb,
                         const unsigned *__restrict__ perm,
-                        pmx_record_t *__restrict__ out, uint32_t *__restrict__ tbuf, int Tmax)
+                        pmx_record_t *__restrict__ out, uint32_t *__restrict__ tbuf, int Tmax,
+                        int track8 /* width 8: report whether some H (boundaries included) leaves [-128, 127] */)
 {
     static_assert(!TR || R == 16, "trace: four packed planes of 4 rows");
     constexpr int RS = (R + 3) / 4 * 4;      // profile bytes reserved per lane (whole dwords)
@@ -540,6 +547,11 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     int res = 0;                           // X-form (skew of column rlen-1) of H(qlen-1, rlen-1)
     v2s bestrow = PK(0); int bestrowj = 0; // sg, reference end free: first max of the last row, UNSKEWED X-form (nb + H)
     v2s bestcol = PK(0); int bestcoli = 0; // sg, query end free: first max of the last column (skew of column rlen-1)
+    // width 8 (`nw_*_8`, `sg*_8`): the reference's narrowest -- and on a CPU fastest -- width reports saturation when some H of the
+    // table leaves the int8 range (oracle/pmx_oracle.c, src/alignment/mod.rs:436-440).  The int16 lanes compute the same table:
+    // a running maximum and minimum of the columns' H over the cells inside the table (virtual rows hold boundary values, which
+    // count; virtual and padding columns are masked) travel with the column skew; the boundary row / column join in closed form.
+    v2s runmax = PK(HA[0] + vExt), runmin = runmax;    // a boundary value of this lane's row (HA: form of column j0 - 1), in the form of its first column j0
 
     auto load_scores = [&](int symA, int symB, int (&wa)[RS / 4], int (&wb)[RS / 4]) {
         const int *sa = reinterpret_cast<const int *>(profA + symA * QPS);
@@ -626,6 +638,19 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 
         // ---- captures ----
         const v2s jv = PK(jj);
+        if (!TR && track8) {                              // (wave-uniform: the other widths pay one scalar branch per step)
+            v2s cmx = PK(Hnew[0]), cmn = PK(Hnew[0]);
+#pragma unroll
+            for (int k = 1; k < R; k += 2) {
+                const int k2 = k + 1 < R ? k + 1 : k;
+                cmx = n_max3f(cmx, PK(Hnew[k]), PK(Hnew[k2]));
+                cmn = n_min3f(cmn, PK(Hnew[k]), PK(Hnew[k2]));
+            }
+            const int inside = m_ult(jv, rlv);            // this lane's column lies in [0, rlen)
+            runmax = PK(n_bfi(inside, I32(n_max3f(runmax, cmx, cmx)), I32(runmax)));
+            runmin = PK(n_bfi(inside, I32(n_min3f(runmin, cmn, cmn)), I32(runmin)));
+            runmax = PK(I32(runmax) + vExt); runmin = PK(I32(runmin) + vExt);      // into the next column's skew
+        }
         const int mLast = m_eq(jv, rl1);                  // this lane is at column rlen-1
         res = n_bfi(mLast, Hout, res);
         if (s2_end) {
@@ -706,6 +731,18 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     const int lastlane = IL ? 2 * (G - 1) + (slot & 1) + 16 * (slot >> 1) : slot * G + G - 1;
     const int resL = __shfl(res, lastlane, 64);
     const int browL = __shfl(I32(bestrow), lastlane, 64), browjL = __shfl(bestrowj, lastlane, 64);
+    int hiA = 0, hiB = 0, loA = 0, loB = 0;                // width 8: true extremes of H over the group's cells (0 = H(-1, -1) counts)
+    if (!TR && track8) {
+        const int un = nb + (T - g + G) * ext - open + ext;                      // X-form of a true 0 in the form the running values ended in
+        hiA = max(0, (I32(runmax) & 0xFFFF) - un); hiB = max(0, (int)((unsigned)I32(runmax) >> 16) - un);
+        loA = min(0, (I32(runmin) & 0xFFFF) - un); loB = min(0, (int)((unsigned)I32(runmin) >> 16) - un);
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            const int lo = IL ? 2 * off : off;
+            hiA = max(hiA, __shfl_xor(hiA, lo, 64)); hiB = max(hiB, __shfl_xor(hiB, lo, 64));
+            loA = min(loA, __shfl_xor(loA, lo, 64)); loB = min(loB, __shfl_xor(loB, lo, 64));
+        }
+    }
     if (g == 0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -717,6 +754,13 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
                 const int corner = (int)(h ? ((unsigned)resL >> 16) : (resL & 0xFFFF)) - unsk;
                 pmx_record_t rec;
                 rec.flags = 0;
+                if (!TR && track8) {
+                    int lo = h ? loB : loA;
+                    const int hi = h ? hiB : hiA;
+                    if (col_pen) lo = min(lo, -(open + (ql - 1) * ext));        // H(i, -1), H(-1, j): the boundary column and row
+                    if (row_pen) lo = min(lo, -(open + (rl - 1) * ext));
+                    if (hi > 127 || lo < -128) rec.flags = PMX_FLAG_SATURATED;
+                }
                 if (!s1_end && !s2_end) { rec.score = corner; rec.end_query = ql - 1; rec.end_ref = rl - 1; }
                 else {
                     int best = -2147483647 - 1, ei = 0, ej = 0;
@@ -1392,7 +1436,8 @@ static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     if (blocks <= 0) return 0;
     hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, FETCH, TRB>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
-                       m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax);
+                       m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax,
+                       TR ? 0 : b.track8);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
@@ -1472,7 +1517,7 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
     // (second generation, scores only: the row above lane 0 is a closed form, so no virtual row is needed and the
     //  query may fill all G * R rows; the first generation and the traceback walk need row -1 to exist)
     if (const int nb = pmx_nwsgv_bias(b, m, open, ext)) {
-        if (b.q_shared && !pmx_env("PMX_NWSG16_NO_SHARED")) {        // profile arm: one profile per workgroup, references from HBM
+        if (b.q_shared && !b.track8 && !pmx_env("PMX_NWSG16_NO_SHARED")) {        // profile arm: one profile per workgroup, references from HBM
 #define TRYQ(GG, RR, NAME)                                                      \
             if (q <= (GG) * (RR)) {                                         \
                 int rc = launch_nwsgq<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
@@ -1486,7 +1531,7 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
             TRYQ(64, 32, "pmx_nwsg16q_kernel<64,32>/shared profile")
 #undef TRYQ
         }
-        if (!b.q_shared && m.msize > 8 && m.msize < 32 && b.n > 2048 && !pmx_env("PMX_NWSG16_NO_MATRIX_LOOKUP")) {   // per-pair, large alphabet
+        if (!b.q_shared && !b.track8 && m.msize > 8 && m.msize < 32 && b.n > 2048 && !pmx_env("PMX_NWSG16_NO_MATRIX_LOOKUP")) {   // per-pair, large alphabet
 #define TRYM(GG, RR, NAME)                                                      \
             if (q <= (GG) * (RR)) {                                             \
                 int rc = launch_nwsgm<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
@@ -1531,6 +1576,7 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
         TRYV(64, 32, "pmx_nwsg16v_kernel<64,32>")
 #undef TRYV
     }
+    if (b.track8) return 1;                                    // (the first-generation kernel does not track the range: general kernel)
     // exact window of the biased lanes: every H, E, F, H-open, E-ext and H(diag)+score stays inside
     const long long lo = -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
     const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);

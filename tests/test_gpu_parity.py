@@ -404,7 +404,7 @@ def test_sw16_long_references_fetch_variant(pkg, orc, alpha):
         pm, om, al, go, ge = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3), DNA, 5, 2
     else:
         pm, om, al, go, ge = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt"), AA, 11, 1
-    for qlo, qhi, n in ((30, 160, 60), (200, 320, 40), (600, 1000, 16)):
+    for qlo, qhi, n in ((30, 160, 60), (200, 320, 40), (600, 1000, 20)):      # (more than 16 pairs: fewer would take pmx_long32_kernel)
         qs = random_seqs(rng, n, qlo, qhi, al)
         rs = [random_seqs(rng, 1, 1000, 4000, al)[0] + mutate(rng, q, 0.15, 0.04, al) + random_seqs(rng, 1, 100, 2500, al)[0] for q in qs]
         rs[0] = rs[0][:1030]
@@ -725,6 +725,64 @@ def test_general_fixed_width_saturation(pkg, orc):
     want = orc.align(0, q, r, 5, 2, om, bits=8)
     got = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).solution_width(8).build().align(q, r)
     assert got.is_saturated() == bool(want.saturated) and want.saturated == 1
+
+
+@pytest.mark.parametrize("gaps", [(5, 2), (1, 1), (11, 1), (0, 0), (3, 0)])
+@pytest.mark.parametrize("n", [300, 4200])
+def test_nwsg_width8_range_tracking_in_the_packed_kernel(pkg, orc, gaps, n):
+    """`nw_striped_8`, `sg*_striped_8` (src/aligner/mod.rs:125-130; saturation: src/alignment/mod.rs:436-440): the packed int16
+    kernel computes the table and tracks the range of H; the flag equals the oracle's rule (some H, boundaries included, outside
+    [-128, 127]) on every pair, and unsaturated pairs carry the exact score and ends.  Lengths straddle the int8 range."""
+    rng = np.random.default_rng(2350 + gaps[0] * 7 + n)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, n, 1, 150)
+    rs = [mutate(rng, q, 0.12, 0.05) if k % 3 else random_seqs(rng, 1, 1, 160)[0] for k, q in enumerate(qs)]
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    idx = np.arange(n)
+    seen = set()
+    for mode, sg, qg, dg in ((0, 15, None, None), (1, 15, None, None), (1, 1 | 8, ["prefix"], ["suffix"]), (1, 2, ["suffix"], []), (1, 4 | 8, [], ["prefix", "suffix"])):
+        b = pkg.Aligner.new().matrix(pm).gap_open(gaps[0]).gap_extend(gaps[1]).solution_width(8)
+        [b.global_, b.semi_global][mode]()
+        if qg is not None:
+            b.allow_query_gaps(qg).allow_ref_gaps(dg)
+        got = b.build().align_batch(qs, rs)
+        assert "pmx_nwsg16v_kernel" in pkg.lib.pmx_last_kernel().decode(), pkg.lib.pmx_last_kernel()
+        want = orc.align_stats_sample(mode, idx, qb, qo, rb, ro, gaps[0], gaps[1], om, sg_flags=sg, bits=8)
+        sat = want[:, 6] == 1
+        bad = np.nonzero((got["flags"] & 1) != want[:, 6])[0]
+        assert len(bad) == 0, (mode, sg, gaps, bad[:5], [(len(qs[k]), len(rs[k])) for k in bad[:5]], want[bad[:5]])
+        ok = ~sat
+        assert (got["score"][ok] == want[ok, 0]).all() and (got["end_query"][ok] == want[ok, 1]).all() and (got["end_ref"][ok] == want[ok, 2]).all()
+        seen |= {bool(x) for x in sat}
+    assert seen == {True, False}
+
+
+def test_nwsg_width8_protein_profile_arm_and_long_references(pkg, orc):
+    rng = np.random.default_rng(2360)
+    pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    q = random_seqs(rng, 1, 12, 12, AA)[0]
+    rs = random_seqs(rng, 3000, 1, 40, AA) + [mutate(rng, q, 0.2, 0.05, AA) for _ in range(200)]
+    rb, ro = orc.pack(rs)
+    idx = np.arange(len(rs))
+    for mode in (0, 1):
+        b = pkg.Aligner.new().matrix(pm).gap_open(11).gap_extend(1).solution_width(8).profile(pkg.Profile.new(q, False, pm))
+        [b.global_, b.semi_global][mode]()
+        got = b.build().align_batch([], rs)
+        assert "pmx_nwsg16v_kernel" in pkg.lib.pmx_last_kernel().decode()
+        want = orc.align_stats_sample(mode, idx, None, None, rb, ro, 11, 1, om, bits=8, shared_query=q)
+        assert ((got["flags"] & 1) == want[:, 6]).all()
+        ok = want[:, 6] == 0
+        assert ok.any() and (~ok).any()
+        assert (got["score"][ok] == want[ok, 0]).all() and (got["end_ref"][ok] == want[ok, 2]).all()
+    # references of >= 1024 symbols (the fetch variant): every pair saturates at 8 bits, one way or the other
+    dm, dom = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 2100, 20, 60); rl = random_seqs(rng, 2100, 1024, 1300)
+    got = pkg.Aligner.new().semi_global().matrix(dm).gap_open(5).gap_extend(2).solution_width(8).build().align_batch(qs, rl)
+    qb, qo = orc.pack(qs); rb2, ro2 = orc.pack(rl)
+    want = orc.align_stats_sample(1, np.arange(0, 2100, 7), qb, qo, rb2, ro2, 5, 2, dom, bits=8)
+    assert ((got["flags"][::7] & 1) == want[:, 6]).all()
+    ok = want[:, 6] == 0
+    assert (got["score"][::7][ok] == want[ok, 0]).all()
 
 
 def test_general_batch_modes_and_stats(pkg, orc):

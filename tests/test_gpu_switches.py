@@ -95,6 +95,15 @@ def _suite(pkg, orc):
     al8 = builder(dna_p, 5, 2, "sw", 8).build()
     (qb, qo), (rb, ro) = packs["dq"], packs["dr"]
     cases.append(("sw/dna/width8", lambda: (rec(al8.align_batch_packed(qb, qo, rb, ro)),)))
+    for mode in ("nw", "sg"):                                       # width 8, global / semi-global: the int16 kernel tracks the range of H
+        al8n = builder(dna_p, 5, 2, mode, 8).build()
+
+        def w8(al8n=al8n):
+            r = al8n.align_batch_packed(qb, qo, rb, ro)
+            sat = (r["flags"] & 1).astype(np.int32)
+            keep = (1 - sat)[:, None]                                 # (score and ends are unspecified where the width saturates)
+            return (rec(r) * keep, sat)
+        cases.append(("%s/dna/width8" % mode, w8))
     alb = builder(dna_p, 5, 2, "nw").build()
     cases.append(("nw/dna/banded", lambda: (rec(alb.align_batch_banded(dq[:400], dr[:400], 12)),)))
     alt = builder(dna_p, 5, 2, "sg").use_table().build()
