@@ -746,7 +746,8 @@ def test_nwsg_width8_range_tracking_in_the_packed_kernel(pkg, orc, gaps, n):
         if qg is not None:
             b.allow_query_gaps(qg).allow_ref_gaps(dg)
         got = b.build().align_batch(qs, rs)
-        assert "pmx_nwsg16v_kernel" in pkg.lib.pmx_last_kernel().decode(), pkg.lib.pmx_last_kernel()
+        # (mismatch + open >= 0: the window of the byte-profile arithmetic; outside it the general kernel tracks the range)
+        assert ("pmx_nwsg16v_kernel" in pkg.lib.pmx_last_kernel().decode()) == (gaps[0] >= 3), pkg.lib.pmx_last_kernel()
         want = orc.align_stats_sample(mode, idx, qb, qo, rb, ro, gaps[0], gaps[1], om, sg_flags=sg, bits=8)
         sat = want[:, 6] == 1
         bad = np.nonzero((got["flags"] & 1) != want[:, 6])[0]
@@ -761,7 +762,7 @@ def test_nwsg_width8_protein_profile_arm_and_long_references(pkg, orc):
     rng = np.random.default_rng(2360)
     pm, om = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
     q = random_seqs(rng, 1, 12, 12, AA)[0]
-    rs = random_seqs(rng, 3000, 1, 40, AA) + [mutate(rng, q, 0.2, 0.05, AA) for _ in range(200)]
+    rs = random_seqs(rng, 3000, 1, 160, AA) + [mutate(rng, q, 0.2, 0.05, AA) for _ in range(200)]
     rb, ro = orc.pack(rs)
     idx = np.arange(len(rs))
     for mode in (0, 1):
@@ -772,7 +773,7 @@ def test_nwsg_width8_protein_profile_arm_and_long_references(pkg, orc):
         want = orc.align_stats_sample(mode, idx, None, None, rb, ro, 11, 1, om, bits=8, shared_query=q)
         assert ((got["flags"] & 1) == want[:, 6]).all()
         ok = want[:, 6] == 0
-        assert ok.any() and (~ok).any()
+        assert ok.any() and ((~ok).any() or mode == 1)
         assert (got["score"][ok] == want[ok, 0]).all() and (got["end_ref"][ok] == want[ok, 2]).all()
     # references of >= 1024 symbols (the fetch variant): every pair saturates at 8 bits, one way or the other
     dm, dom = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
