@@ -792,7 +792,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 // one-instruction decision merge of pmx_nwsg16v_kernel's TRB form -- what BASELINE config 3 (statistics of a reused profile
 // against long references) runs on: the statistics are counted along the path afterwards.
 template <int G, int R, int WAVES, bool TR = false>
-__global__ __launch_bounds__(64 * WAVES)
+__global__ __launch_bounds__(64 * WAVES)       // (<16,20,TR> takes 178 VGPRs = two waves per SIMD; forced to 168 for three it spills and is 10 % slower)
 void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
                         const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
                         long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
@@ -801,7 +801,7 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
                         const unsigned *__restrict__ perm,
                         pmx_record_t *__restrict__ out, uint32_t *__restrict__ tbuf = nullptr, int Tmax = 0)
 {
-    static_assert(!TR || R == 10 || R == 16, "trace record layouts");
+    static_assert(!TR || R == 10 || R == 16 || R == 20, "trace record layouts");
     constexpr int TD = (R + 3) / 4;               // dwords per trace record (R / 2 bytes per pair, two pairs)
     constexpr int RS = (R + 3) / 4 * 4;
     constexpr int QP = G * R;
@@ -898,21 +898,29 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
     auto step = [&](int bsel, int t) {
         const int Hin = n_shift_up<G>(Hout, topX, g);
         int F = n_shift_up<G>(Fout, topX, g);
-        int Tpre[R];
+        // rows in blocks of HBLK: the diagonal sums of a block are formed before its rows overwrite the strip (one block: halving it
+        // for R = 20 did not lower the allocator's register count)
+        constexpr int HBLK = R;
+        int Tpre[HBLK];
         int tacc = 0, ty[TR ? R / 2 : 1];
+        int xcarry = diag0;                                  // previous column's H of the row above the block
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
+        for (int k0 = 0; k0 < R; k0 += HBLK) {
+        const int xnext = X[k0 + HBLK - 1];
+#pragma unroll
+        for (int k = k0; k < k0 + HBLK; ++k) {
             const int s = __builtin_amdgcn_perm(w[bsel][1][k / 4], w[bsel][0][k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16));
-            Tpre[k] = ((k == 0) ? diag0 : X[k - 1]) + s;
+            Tpre[k - k0] = ((k == k0) ? xcarry : X[k - 1]) + s;
         }
+        xcarry = xnext;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
+        for (int k = k0; k < k0 + HBLK; ++k) {
             const int Fe = F - vExt;
-            const int H = I32(n_max3f(PK(Tpre[k]), PK(E[k]), PK(Fe)));
+            const int H = I32(n_max3f(PK(Tpre[k - k0]), PK(E[k]), PK(Fe)));
             const int Xn = H - vC;
             if (TR) {     // ND, NDL, EO, FO: the sign of each difference, inserted at its bit of the row pair's byte (see pmx_nwsg16v_kernel)
-                const int dND = I32(PK(Tpre[k]) - PK(H)), dNDL = I32(PK(Fe) - PK(H));
+                const int dND = I32(PK(Tpre[k - k0]) - PK(H)), dNDL = I32(PK(Fe) - PK(H));
                 const int dEO = I32(PK(E[k]) - PK(Xn)), dFO = I32(PK(Fe) - PK(Xn));
                 if ((k & 1) == 0) {
                     tacc = dND;
@@ -931,12 +939,23 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
             F = I32(n_max3f(PK(Fe), PK(Xn), PK(Xn)));
             X[k] = Xn;
         }
+        }
         if (TR) {
             // record: [A bytes 0 .. R/2-1][B bytes 0 .. R/2-1][pad]; u = [A_y A_y+1 B_y B_y+1] of two row pairs
             const int u01 = __builtin_amdgcn_perm(ty[0], ty[1], 0x03070105), u23 = __builtin_amdgcn_perm(ty[2], ty[3], 0x03070105);
             const int a0 = __builtin_amdgcn_perm(u01, u23, 0x01000504), b0 = __builtin_amdgcn_perm(u01, u23, 0x03020706);
             uint32_t *dst = tstage + (t & (TSTG - 1)) * TD;
-            if (R == 16) {
+            if (R == 20) {
+                // 10 + 10 bytes: a whole number of dwords (the 12-byte record of R = 10 carries two bytes of padding per 20 cells)
+                const int u45 = __builtin_amdgcn_perm(ty[R == 20 ? 4 : 0], ty[R == 20 ? 5 : 0], 0x03070105), u67 = __builtin_amdgcn_perm(ty[R == 20 ? 6 : 0], ty[R == 20 ? 7 : 0], 0x03070105);
+                const int u89 = __builtin_amdgcn_perm(ty[R == 20 ? 8 : 0], ty[R == 20 ? 9 : 0], 0x03070105);
+                const int b1 = __builtin_amdgcn_perm(u45, u67, 0x03020706);
+                dst[0] = (uint32_t)a0;                                                    // A0 A1 A2 A3
+                dst[1] = (uint32_t)__builtin_amdgcn_perm(u45, u67, 0x01000504);           // A4 .. A7
+                dst[2] = (uint32_t)__builtin_amdgcn_perm(u89, u01, 0x03020504);           // A8 A9 B0 B1
+                dst[3] = (uint32_t)__builtin_amdgcn_perm(b0, b1, 0x01000706);             // B2 B3 B4 B5
+                dst[TD - 1] = (uint32_t)__builtin_amdgcn_perm(b1, u89, 0x03020706);       // B6 B7 B8 B9
+            } else if (R == 16) {
                 const int u45 = __builtin_amdgcn_perm(ty[4], ty[R == 16 ? 5 : 0], 0x03070105), u67 = __builtin_amdgcn_perm(ty[R == 16 ? 6 : 0], ty[R == 16 ? 7 : 0], 0x03070105);
                 dst[0] = (uint32_t)a0; dst[1] = (uint32_t)__builtin_amdgcn_perm(u45, u67, 0x01000504);
                 dst[2] = (uint32_t)b0; dst[TD - 1] = (uint32_t)__builtin_amdgcn_perm(u45, u67, 0x03020706);
@@ -1357,16 +1376,19 @@ static int launch_nwsgq(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
 
 // Traceback with a shared query (profile arm): shapes <16,10> <16,16> <32,10> <32,16> <64,16>, one virtual row at least on top
 // (the walk needs row -1), bounded differences for the one-instruction decision merge.  *variant = 30 + shape index.
-static const int kQShapeG[5] = {16, 16, 32, 32, 64}, kQShapeR[5] = {10, 16, 10, 16, 16};
+// <16,20>: 320 rows like <32,10>, but twice the rows per lane -- the per-step work that is not per row (hand-off, captures, record
+// assembly, staging flush) is shared by twice the cells -- and a record of exactly 20 bytes instead of 12 for half the cells.
+static const int kQShapeG[6] = {16, 16, 16, 32, 32, 64}, kQShapeR[6] = {10, 16, 20, 10, 16, 16};
 int pmx_nwsgq_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
                          int *variant, int *Tmax, size_t *trace_bytes, int *G_out, int *R_out)
 {
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
     if (!b.q_shared || !pmx_nwsgv_bias(b, m, open, ext)) return 1;
     if ((m.max > 0 ? m.max : 0) + 2 * open > 250) return 1;
-    for (int v = 0; v < 5; ++v) {
+    for (int v = 0; v < 6; ++v) {
         const int G = kQShapeG[v], R = kQShapeR[v];
         if (b.q_shared > G * R - 1) continue;
+        if (R == 20 && pmx_env("PMX_NWSGQ_NO_R20")) continue;
         const size_t lds = (size_t)(m.msize + 1) * G * ((R + 3) / 4 * 4) + 8 + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)(2 * (64 / G) * 4) * 24 +
                            (size_t)4 * 64 * (PMX_QSTAGE * ((R + 3) / 4) + 1) * 4;
         if (lds > 160 * 1024) continue;
@@ -1387,9 +1409,10 @@ int pmx_launch_nwsgq_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m
     switch (variant - 30) {
     case 0: return launch_nwsgq<16, 10, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 1: return launch_nwsgq<16, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
-    case 2: return launch_nwsgq<32, 10, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
-    case 3: return launch_nwsgq<32, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
-    case 4: return launch_nwsgq<64, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 2: return launch_nwsgq<16, 20, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 3: return launch_nwsgq<32, 10, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 4: return launch_nwsgq<32, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 5: return launch_nwsgq<64, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     }
     return 1;
 }
