@@ -1136,6 +1136,9 @@ extern "C" const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen,
         cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && cfg->open >= cfg->extend && cfg->extend >= 1 &&
         max_qlen <= 1024 && cfg->matrix->size < PMX_MAX_FAST_MSIZE)
         return "pmx_stats16_kernel";
+    if ((cfg->want & ~PMX_WANT_SORTED) == 0 && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && cfg->matrix->size <= 64 &&
+        (cfg->mode == PMX_MODE_SW || (cfg->width != 8 && cfg->width != 16)))
+        return "pmx_long32_kernel";
     return "pmx_general_kernel";
 }
 
@@ -1322,6 +1325,50 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
     return 0;
 }
 
+// pmx_long32_kernel over a batch, in chunks of bounded scratch: 0 done, 1 not eligible, < 0 error.  Score and end positions, 32-bit
+// lanes, any gap model (open < extend included), alphabets up to 64 letters, no limit on either length.  Widths: local -- any
+// (saturation = a score beyond the width); global / semi-global -- sat, 32, 64, or a fixed width whose range the boundary row /
+// column already leaves (one pair: its lengths are known here); a fixed width that needs the range of H tracked is not served.
+static int long_batch(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch &b0, int64_t n, int32_t max_qlen, int32_t max_rlen,
+                      pmx_record_t *d_out, hipStream_t st)
+{
+    if (pmx_env("PMX_NO_LONG_KERNEL") || cfg->matrix->type != PARASAIL_MATRIX_TYPE_SQUARE) return 1;
+    int force_sat = 0, sat_above = 2147483647;
+    const int wmax = cfg->width == 8 ? 127 : cfg->width == 16 ? 32767 : 2147483647;
+    if (cfg->mode == PMX_MODE_SW) sat_above = wmax;
+    else if (cfg->width == 8 || cfg->width == 16) {
+        const bool pen_col = cfg->mode == PMX_MODE_NW || !(cfg->sg_flags & PMX_SG_QB), pen_row = cfg->mode == PMX_MODE_NW || !(cfg->sg_flags & PMX_SG_DB);
+        const long long lo = std::min(pen_col ? -((long long)cfg->open + (long long)(max_qlen - 1) * cfg->extend) : 0LL,
+                                      pen_row ? -((long long)cfg->open + (long long)(max_rlen - 1) * cfg->extend) : 0LL);
+        if (n == 1 && lo < -(long long)wmax - 1) force_sat = 1; else return 1;     // (inside the range: the general kernel tracks min / max H)
+    }
+    int R = 4; long long bstride = 0; int nbmax = 0;
+    size_t per_pair = pmx_long_scratch_bytes(1, max_qlen, max_rlen, R, &bstride, &nbmax);
+    if (per_pair > ((size_t)4 << 30)) { R = 16; per_pair = pmx_long_scratch_bytes(1, max_qlen, max_rlen, R, &bstride, &nbmax); }
+    size_t fb = 0, tb = 0;
+    if (hipMemGetInfo(&fb, &tb) != hipSuccess) fb = 0;
+    size_t budget = std::min<size_t>((size_t)4 << 30, fb / 4) + ((size_t)64 << 20);
+    if (const char *e = pmx_env("PMX_LONG_CHUNK_BYTES")) budget = (size_t)atof(e);        // tests force several chunks
+    if (per_pair > budget && !pmx_env("PMX_LONG_CHUNK_BYTES")) return 1;
+    int64_t chunk = (int64_t)(budget / per_pair);
+    if (chunk < 1) chunk = 1;
+    if (chunk > n) chunk = n;
+    void *scr = nullptr;
+    if (scratch_reserve((size_t)chunk * per_pair, &scr, SCR_LONG)) return 1;
+    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+        PmxBatch b = b0;
+        b.perm = nullptr;                                  // (a processing order is a hint: records are indexed by pair)
+        b.n = (n - c0 < chunk) ? n - c0 : chunk;
+        if (!b.q_shared) b.qoff = b0.qoff + c0;
+        b.roff = b0.roff + c0;
+        const int rc = pmx_launch_long(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, R, scr, d_out + c0, sat_above, force_sat, st);
+        if (rc < 0) { set_err("long-pair kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
+        if (rc) return c0 == 0 ? 1 : (set_err("long-pair kernel refused a later chunk"), -1);
+    }
+    g_last_kernel = R == 4 ? "pmx_long32_kernel<4>/bands across the chip" : "pmx_long32_kernel<16>/bands across the chip";
+    return 0;
+}
+
 // Device-resident batch.  q_shared > 0: every pair uses the one query d_qbuf[0..q_shared) (profile arm).
 static int run_batch_device(const pmx_config_t *cfg, int64_t n,
                             const uint8_t *d_qbuf, const int64_t *d_qoff, int q_shared,
@@ -1346,33 +1393,11 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         const int rc = pmx_build_length_perm(d_roff, n, scr, &b.perm, st);
         if (rc < 0) { set_err("length sort failed (%d)", rc); return rc; }
     }
-    // Few long pairs (one align() call on kilobases: src/aligner/mod.rs:397-430 has no length limit): the query's bands spread
-    // over the chip (pmx_long.hip).  Widths: local -- any (saturation = a score beyond the width); global / semi-global -- sat, 32,
-    // 64, or a fixed width whose range the boundary row / column already leaves (one pair: its lengths are known here).
-    if (want == 0 && n <= 16 && !b.perm && cfg->matrix->type == PARASAIL_MATRIX_TYPE_SQUARE && max_qlen >= 512 &&
-        (long long)max_qlen * max_rlen >= (3LL << 20) && !pmx_env("PMX_NO_LONG_KERNEL")) {
-        bool ok = true; int force_sat = 0, sat_above = 2147483647;
-        const int wmax = cfg->width == 8 ? 127 : cfg->width == 16 ? 32767 : 2147483647;
-        if (cfg->mode == PMX_MODE_SW) sat_above = wmax;
-        else if (cfg->width == 8 || cfg->width == 16) {
-            const bool pen_col = cfg->mode == PMX_MODE_NW || !(cfg->sg_flags & PMX_SG_QB), pen_row = cfg->mode == PMX_MODE_NW || !(cfg->sg_flags & PMX_SG_DB);
-            const long long lo = std::min(pen_col ? -((long long)cfg->open + (long long)(max_qlen - 1) * cfg->extend) : 0LL,
-                                          pen_row ? -((long long)cfg->open + (long long)(max_rlen - 1) * cfg->extend) : 0LL);
-            if (n == 1 && lo < -(long long)wmax - 1) force_sat = 1; else ok = false;     // (inside the range: the general kernel tracks min / max H)
-        }
-        if (ok) {
-            int R = 4; long long bstride = 0; int nbmax = 0;
-            size_t bytes = pmx_long_scratch_bytes(n, max_qlen, max_rlen, R, &bstride, &nbmax);
-            if (bytes > ((size_t)4 << 30)) { R = 16; bytes = pmx_long_scratch_bytes(n, max_qlen, max_rlen, R, &bstride, &nbmax); }
-            size_t fb = 0, tb = 0;
-            if (hipMemGetInfo(&fb, &tb) != hipSuccess) fb = 0;
-            void *scr = nullptr;
-            if (bytes <= fb / 4 + ((size_t)64 << 20) && scratch_reserve(bytes, &scr, SCR_LONG) == 0) {
-                const int rc = pmx_launch_long(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, R, scr, d_out, sat_above, force_sat, st);
-                if (rc < 0) { set_err("long-pair kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
-                if (rc == 0) { g_last_kernel = R == 4 ? "pmx_long32_kernel<4>/bands across the chip" : "pmx_long32_kernel<16>/bands across the chip"; return 0; }
-            }
-        }
+    // Few long pairs (one align() call on kilobases: src/aligner/mod.rs:397-430 has no length limit), or queries beyond the packed
+    // kernels' 2 048 rows in any number: the query's bands spread over the chip (pmx_long.hip).
+    if (want == 0 && ((n <= 16 && max_qlen >= 512 && (long long)max_qlen * max_rlen >= (3LL << 20)) || max_qlen > 2048)) {
+        const int rc = long_batch(cfg, dm, b, n, max_qlen, max_rlen, d_out, st);
+        if (rc <= 0) return rc;
     }
     if (fast_sw_eligible(cfg)) {
         b.q_has_wildcard = q_shared ? q_shared_wild : 0;
@@ -1510,6 +1535,12 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         if (rc == 0) return 0;     // the host-side range proof makes overflow impossible: no promotion pass
     }
     if (cfg->matrix->type == PARASAIL_MATRIX_TYPE_PSSM) { set_err("PSSM matrices are single-pair only"); return -1; }
+    if (want == 0) {
+        // Outside every packed kernel's window (gap models with open < extend, alphabets of 32 and more letters, value ranges the
+        // int16 lanes cannot prove): the 32-bit band kernel, one wave per 256 query rows -- several times the general kernel's rate
+        const int rc = long_batch(cfg, dm, b, n, max_qlen, max_rlen, d_out, st);
+        if (rc <= 0) return rc;
+    }
     const int rcg = general_batch(cfg, dm, n, d_qbuf, d_qoff, q_shared, d_rbuf, d_roff, max_rlen, -1, nullptr,
                                   (want & PMX_WANT_STATS) != 0, d_out, d_stats_out, st, max_qlen);
     if (rcg) return rcg;

@@ -287,7 +287,7 @@ size_t pmx_long_scratch_bytes(long long n, int max_qlen, int max_rlen, int R, lo
 {
     const int BR = 64 * R;
     *nbmax = (max_qlen + BR - 1) / BR;
-    *bstride = (((long long)max_rlen + 63) & ~63LL) + 64;
+    *bstride = *nbmax > 1 ? (((long long)max_rlen + 63) & ~63LL) + 64 : 0;      // one band per pair: nothing is handed on
     return (size_t)n * (size_t)*nbmax * ((size_t)*bstride * 8 + 32);
 }
 
@@ -295,7 +295,7 @@ size_t pmx_long_scratch_bytes(long long n, int max_qlen, int max_rlen, int R, lo
 int pmx_launch_long(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int R,
                     void *scratch, pmx_record_t *d_out, int sat_above, int force_sat, hipStream_t stream)
 {
-    if (b.perm || m.msize > PMX_MAX_FAST_MSIZE) return 1;
+    if (b.perm || m.msize > 64) return 1;
     if (m.max + open > 32000 || m.min + open < -16000 || open < 0 || ext < 0) return 1;      // int16 profile entries
     if ((long long)(b.max_qlen + b.max_rlen) * (long long)(ext > open ? ext : open) > (1LL << 29)) return 1;   // boundary values stay above LONG_NEG
     PmxLongArgs a;
@@ -309,10 +309,11 @@ int pmx_launch_long(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_f
     a.cand = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scratch) + bound_bytes);
     a.out = d_out; a.sat_above = sat_above; a.force_sat = force_sat;
     (void)bytes;
-    hipError_t e = hipMemsetAsync(scratch, 0x80, bound_bytes, stream);
+    hipError_t e = bound_bytes ? hipMemsetAsync(scratch, 0x80, bound_bytes, stream) : hipSuccess;
     if (e != hipSuccess) return -(int)e;
     const int BR = 64 * R;
     const size_t lds = (size_t)(m.msize + 1) * BR * 2 + (size_t)m.msize * m.msize * 2 + 256 + 16;
+    if (lds > 160 * 1024) return 1;
     const long long blocks = b.n * nbmax;
     if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return 1;
 #define LONG_LAUNCH(RR, MM) do { \

@@ -211,7 +211,9 @@ def test_error_paths_without_gpu(pkg):
     assert pkg.lib.pmx_kernel_for(C.byref(cfg), 300, 5000) == b"pmx_stats16_kernel"
     cfg = pkg.pmx_config_t(pkg.MODE_NW, 0, 5, 2, 8, 0, al.matrix.inner)           # width 8: the int16 kernel tracks the range
     assert pkg.lib.pmx_kernel_for(C.byref(cfg), 150, 150) == b"pmx_nwsg16_kernel"
-    cfg = pkg.pmx_config_t(pkg.MODE_NW, 0, 2, 5, 16, 0, al.matrix.inner)           # open < extend -> general kernel
+    cfg = pkg.pmx_config_t(pkg.MODE_NW, 0, 2, 5, 32, 0, al.matrix.inner)           # open < extend -> the 32-bit band kernel
+    assert pkg.lib.pmx_kernel_for(C.byref(cfg), 150, 150) == b"pmx_long32_kernel"
+    cfg = pkg.pmx_config_t(pkg.MODE_NW, 0, 2, 5, 16, pkg.WANT_STATS, al.matrix.inner)   # ... with statistics: general kernel
     assert pkg.lib.pmx_kernel_for(C.byref(cfg), 150, 150) == b"pmx_general_kernel"
 
 

@@ -139,3 +139,50 @@ def test_short_query_against_a_very_long_reference_and_the_switch(pkg, orc, monk
         assert LONG not in pkg.lib.pmx_last_kernel().decode()
         monkeypatch.delenv("PMX_NO_LONG_KERNEL")
         assert (res2.get_score(), res2.get_end_query(), res2.get_end_ref()) == (w.score, w.end_query, w.end_ref)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_batches_outside_every_packed_window_take_the_band_kernel(pkg, orc, mode, monkeypatch):
+    """Score-only batches no packed int16 kernel serves -- a gap model with open < extend, an alphabet of 40 letters, queries beyond
+    2 048 rows in numbers -- run in pmx_long32_kernel (one wave per 256 query rows, any number of pairs, chunks of bounded
+    scratch) instead of the general kernel; every pair against the oracle."""
+    rng = np.random.default_rng(9995 + mode)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 3000, 1, 300)
+    rs = [mutate(rng, q, 0.1, 0.04) if k % 2 else random_seqs(rng, 1, 1, 350)[0] for k, q in enumerate(qs)]
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    got = _rec(_builder(pkg, pm, 2, 5, mode, 32).build().align_batch(qs, rs))                       # open < extend
+    assert (LONG in pkg.lib.pmx_last_kernel().decode()) == (mode != 2), pkg.lib.pmx_last_kernel()   # (the local packed kernel's max3 variant needs no open >= extend)
+    assert (got == orc.align_batch(mode, qb, qo, rb, ro, 2, 5, om)).all()
+    # 40 letters
+    letters = bytes(range(65, 91)) + b"0123456789@+=?"                    # (the mapper folds case: 40 distinct symbols without lower case)
+    rows = np.random.default_rng(5).integers(-4, 6, size=(41, 41))
+    rows = np.minimum(rows, rows.T)
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as fh:
+        names = [chr(c) for c in letters] + ["*"]
+        fh.write("   " + "  ".join(names) + "\n")
+        for i, nm in enumerate(names):
+            fh.write(nm + " " + " ".join("%3d" % v for v in rows[i]) + "\n")
+        path = fh.name
+    try:
+        pm40 = pkg.Matrix.from_file(path)
+        al40 = np.frombuffer(letters, dtype=np.uint8)
+        q40 = random_seqs(rng, 500, 5, 200, al40); r40 = random_seqs(rng, 500, 5, 260, al40)
+        got = _rec(_builder(pkg, pm40, 6, 1, mode).build().align_batch(q40, r40))
+        assert LONG in pkg.lib.pmx_last_kernel().decode(), pkg.lib.pmx_last_kernel()
+        om40 = orc.Matrix(rows.astype(np.int32), np.array([letters.find(bytes([c])) if bytes([c]) in letters else 40 for c in range(256)], dtype=np.int32))
+        qb4, qo4 = orc.pack(q40); rb4, ro4 = orc.pack(r40)
+        assert (got == orc.align_batch(mode, qb4, qo4, rb4, ro4, 6, 1, om40)).all()
+    finally:
+        os.remove(path)
+    # 40 pairs of 2 100 - 2 600 rows, in chunks of a few pairs each
+    lq = random_seqs(rng, 40, 2100, 2600); lr = [mutate(rng, q, 0.1, 0.03)[:2400] for q in lq]
+    qb, qo = orc.pack(lq); rb, ro = orc.pack(lr)
+    want = orc.align_batch(mode, qb, qo, rb, ro, 5, 2, om)
+    for chunk in (None, "2.5e6"):
+        if chunk:
+            monkeypatch.setenv("PMX_LONG_CHUNK_BYTES", chunk)
+        got = _rec(_builder(pkg, pm, 5, 2, mode).build().align_batch(lq, lr))
+        assert LONG in pkg.lib.pmx_last_kernel().decode()
+        assert (got == want).all(), chunk

@@ -630,7 +630,7 @@ def test_nwsg16_falls_back_outside_the_exact_window(pkg, orc):
     qs = random_seqs(rng, 20, 100, 150)
     rs = random_seqs(rng, 20, 100, 150)
     _nwsg_case(pkg, orc, 0, None, qs, rs, 60, 50, pm, om, expect_kernel=None)      # lo bound ~ -15000
-    _nwsg_case(pkg, orc, 0, None, qs, rs, 2, 5, pm, om, expect_kernel="pmx_general_kernel")   # open < extend
+    _nwsg_case(pkg, orc, 0, None, qs, rs, 2, 5, pm, om, expect_kernel="pmx_general_kernel")   # open < extend at a fixed width: the general kernel tracks the range (sat / 32 / 64: pmx_long32_kernel)
 
 
 # --------------------------------------------------------------------- general kernel ----

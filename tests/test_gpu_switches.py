@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 # switches whose alternative is only reachable together with another one (the partner is set too)
 PARTNERS = {"PMX_STATS_BY_TRACE_ANY": ["PMX_STATS_BY_TRACE"]}
 VALUES = {"PMX_SW16_VARIANT": ["0", "1", "2"], "PMX_STATS_CHUNK_BYTES": ["3e6"], "PMX_CIGAR_CHUNK_BYTES": ["3e6"],
-          "PMX_GENERAL_CHUNK_BYTES": ["1"]}                      # (its batches: tests/test_gpu_tables.py)
+          "PMX_GENERAL_CHUNK_BYTES": ["1"], "PMX_LONG_CHUNK_BYTES": ["1e6"]}                      # (its batches: tests/test_gpu_tables.py)
 NOT_A_DISPATCH_CHOICE = {"PMX_MATRIX_DIR", "PMX_TIMING", "PMX_CIGAR_SWAP_ID"}          # a path (tests/test_abi.py) and a diagnostics print
 
 
@@ -76,6 +76,16 @@ def _suite(pkg, orc):
             r, s = alps.align_batch_packed(None, None, rb, ro)
             return rec(r), np.stack([s[f] for f in s.dtype.names], axis=1)
         cases.append(("%s/profile/stats" % mode, pstats))
+    # profile arm with statistics, a 300-aa query (BASELINE config 3's shape: the <16,20> traceback sweep) against short references
+    q300 = random_seqs(rng, 1, 300, 300, AA)[0]
+    r300 = [mutate(rng, q300, 0.3, 0.05, AA) if k % 2 else random_seqs(rng, 1, 200, 500, AA)[0] for k in range(700)]
+    (rb3, ro3) = orc.pack(r300)
+    alp3 = builder(b62_p, 11, 1, "nw").profile(pkg.Profile.new(q300, True, b62_p)).build()
+
+    def pstats300():
+        r, st = alp3.align_batch_packed(None, None, rb3, ro3)
+        return rec(r), np.stack([st[f] for f in st.dtype.names], axis=1)
+    cases.append(("nw/profile300/stats", pstats300))
     # equal-length reads (no length sort: the perm-table kernel), small statistics batches, long protein references
     uq = random_seqs(rng, 4200, 150, 150); ur = random_seqs(rng, 4200, 150, 150)      # (>= 4096 pairs: the kernel's own retry list)
     (uqb, uqo), (urb, uro) = orc.pack(uq), orc.pack(ur)
