@@ -17,6 +17,25 @@ d = [torch.from_numpy(x).to(dev) for x in (qbuf, qoff, rbuf, roff)]
 out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
 m = pkg.Matrix.create(b"ACGT", 2, -3)
 stream = torch.cuda.current_stream(dev)
+# a gap model with open < extend (no packed kernel serves global / semi-global there): the 32-bit band kernel, against the general kernel
+for mode, name in ((pkg.MODE_NW, "nw"), (pkg.MODE_SG, "sg")):
+    for env in (None, "PMX_NO_LONG_KERNEL"):
+        if env:
+            os.environ[env] = "1"
+        cfg = pkg.pmx_config_t(mode, pkg.SG_ALL, 2, 5, 32, 0, m.inner)
+        run = lambda: pkg.align_batch_device(cfg, n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 150, 150,
+                                             out.data_ptr(), None, stream.cuda_stream)
+        run(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(3):
+            run()
+        e1.record(stream); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        print("%s_striped_32 open 2 < extend 5 %-18s %8.3f ms  %8.1f GCUPS  %s" % (name, env or "", ms, n * 22500 / ms / 1e6,
+                                                                             pkg.lib.pmx_last_kernel().decode()), flush=True)
+        if env:
+            del os.environ[env]
 for mode, name in ((pkg.MODE_NW, "nw"), (pkg.MODE_SG, "sg"), (pkg.MODE_SW, "sw")):
     for width in (16, 8):
         for env in ((None,) if width == 16 or mode == pkg.MODE_SW else (None, "PMX_NWSG8_GENERAL")):
