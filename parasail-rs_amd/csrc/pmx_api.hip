@@ -1498,6 +1498,9 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
                 if (two && trace_ws_init()) return -1;
                 uint32_t *tbuf = nullptr;
                 if (scratch_reserve(cbytes * (two ? 2 : 1), (void **)&tbuf, SCR_TRACE)) return -1;
+                const size_t fstride = (size_t)chunk / 2 + 16;           // per-block flags of a chunk's sweep, two sets (as in cigar_device_run)
+                int *bflags = nullptr;
+                if (scratch_reserve(2 * fstride * sizeof(int), (void **)&bflags, SCR_RETRY)) return -1;
                 // as in the batch CIGAR entry: two trace buffers, the counting walk of chunk c on the walk stream beside the sweep of
                 // chunk c + 1, sweeps alternating between the caller's stream and an internal one
                 if (two) { HIP_OR_RET(hipEventRecord(g_tws.start, st)); HIP_OR_RET(hipStreamWaitEvent(g_tws.aux, g_tws.start, 0)); }
@@ -1506,6 +1509,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
                     PmxBatch bc = bt;
                     bc.n = (n - c0 < chunk) ? n - c0 : chunk;
                     bc.qoff = d_qoff + c0; bc.roff = d_roff + c0;
+                    bc.blockflag = bflags + (size_t)(idx & 1) * fstride;
                     const hipStream_t sws = (two && (idx & 1)) ? g_tws.aux : st;
                     if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(sws, g_tws.walk_done[idx & 1], 0));
                     PmxWalkSplit sp = {two ? g_tws.walk : st, g_tws.sweep_done[idx & 1], two ? g_tws.walk_done[idx & 1] : nullptr, 0, nullptr};
@@ -1530,6 +1534,11 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         // (width 8: the same int16 kernels, which then also track the range of H for the saturation flag -- the reference's
         //  narrowest width is its fastest on a CPU; it must not be the slow road here)
         b.track8 = cfg->width == 8;
+        if (dm.d.msize <= 5 && n >= 2048 && !b.track8 && !q_shared) {       // per-block flags: lets the launcher try the perm-table form first
+            void *scr = nullptr;
+            if (scratch_reserve(((size_t)n / 2 + 16) * sizeof(int), &scr, SCR_RETRY)) return -1;
+            b.blockflag = (int *)scr;
+        }
         const int rc = pmx_launch_nwsg16(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, d_out, st, &g_last_kernel);
         if (rc < 0) { set_err("nwsg16 launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
         if (rc == 0) return 0;     // the host-side range proof makes overflow impossible: no promotion pass
@@ -2043,12 +2052,14 @@ static int cigar_device_run(const pmx_config_t *cfg, const DevMat &dm, int64_t n
     const bool two = chunk < n && !pmx_env("PMX_CIGAR_NO_OVERLAP");     // (diagnostics: sweep and walk back to back on one stream)
     uint32_t *tbuf = nullptr, *dops = nullptr; unsigned char *misc = nullptr;
     const size_t scan_bytes = pmx_text_scan_scratch_bytes(n);
-    const size_t misc_bytes = (size_t)(4 * n + 2) * sizeof(int32_t) + 256 + scan_bytes;
+    const size_t fstride = (size_t)chunk / 2 + 16;           // per-block flags of a chunk's sweep (perm-table form / LDS-profile form), two sets
+    const size_t misc_bytes = (size_t)(4 * n + 2) * sizeof(int32_t) + 256 + scan_bytes + 256 + 2 * fstride * sizeof(int);
     if (scratch_reserve(cbytes * (two ? 2 : 1), (void **)&tbuf, SCR_TRACE) ||
         scratch_reserve((size_t)n * ((size_t)mq + mr + 1) * sizeof(uint32_t), (void **)&dops, SCR_OPS) ||
         scratch_reserve(misc_bytes, (void **)&misc, SCR_CIG)) return -1;
     int32_t *nops = (int32_t *)misc, *beg = nops + n, *textlen = beg + 2 * n;
     void *scan_tmp = (void *)(((uintptr_t)(textlen + n + 2) + 255) & ~(uintptr_t)255);
+    int *bflags = (int *)(((uintptr_t)scan_tmp + scan_bytes + 255) & ~(uintptr_t)255);
     // sweeps of consecutive chunks alternate between the caller's stream and an internal one (the tail of one launch is
     // backfilled by the next); every walk runs on the high-priority walk stream after its sweep
     if (two) { HIP_OR_RET(hipEventRecord(g_tws.start, st)); HIP_OR_RET(hipStreamWaitEvent(g_tws.aux, g_tws.start, 0)); }
@@ -2057,6 +2068,7 @@ static int cigar_device_run(const pmx_config_t *cfg, const DevMat &dm, int64_t n
         PmxBatch bk = b;
         bk.n = (n - c0 < chunk) ? n - c0 : chunk;
         bk.qoff = d_qoff + c0; bk.roff = d_roff + c0;
+        bk.blockflag = bflags + (size_t)(idx & 1) * fstride;
         const hipStream_t sws = (two && (idx & 1)) ? g_tws.aux : st;
         if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(sws, g_tws.walk_done[idx & 1], 0));     // this trace buffer's last walk is done
         PmxWalkSplit sp = {two ? g_tws.walk : st, g_tws.sweep_done[idx & 1], two ? g_tws.walk_done[idx & 1] : nullptr,

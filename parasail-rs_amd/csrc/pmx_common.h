@@ -32,6 +32,8 @@ struct PmxBatch {
     int sat_above;           // sw16 only, 0 = off: scores above this set PMX_FLAG_SATURATED (width 8: 127; local H >= 0, so the
                              //   maximum H is the score and the oracle's saturation rule needs nothing else)
     int track8;              // nwsg16v only: width 8 -- track the range of H and flag pairs that leave [-128, 127]
+    int *blockflag;          // nwsg16v only, optional scratch of (n + 15) / 2 ints: lets the launcher run the perm-table form first, which
+                             //   marks the blocks (of 2 * 64 / G pairs) it leaves to the LDS-profile form; the walk reads the flags too
 };
 #define PMX_FLAG_RETRY16 4   // internal record flag: redo with the LDS-profile variant of the fast kernel
 
@@ -99,7 +101,7 @@ int pmx_trace16_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int ope
 int pmx_launch_walkp(int gsel, int R, const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext, int Tmax, int top_aligned,
                      pmx_stats_t *stats_out, int row_pen, int col_pen, const uint32_t *tbuf, const pmx_record_t *recs,
                      uint32_t *ops, const int64_t *ops_off, long long ops_base, int32_t *nops, int32_t *beg, int32_t *textlen,
-                     hipStream_t stream);
+                     hipStream_t stream, const int *blockflag = nullptr /* per sweep block: 0 = top-aligned rows (perm-table sweep) */);
 // Optional second stream for the walk (device CIGAR entry: the walk of chunk c runs beside the sweep of chunk c+1).
 struct PmxWalkSplit {
     hipStream_t walk_stream;   // == the sweep's stream: no split

@@ -403,8 +403,19 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
 //     decisions chain through one register (4 v_pk_sub_i16 + 3.5 v_bfi_b32 per row), one v_perm_b32 per four rows packs the top bytes.
 //   * FETCH (long references): reference symbols are not staged in LDS, each lane fetches its next symbols from HBM
 //     two steps ahead (see pmx_sw16q.hip); the staged copies of four 5-kaa references would halve the occupancy.
-template <int G, int R, bool TR, bool FETCH = false, bool TRB = false>
-__global__ __launch_bounds__(64)
+//   * PT (alphabets of <= 4 letters + wildcard, as pmx_sw16.hip's VAR 6): NO LDS profile -- the v_perm that widened the profile
+//     bytes is the lookup itself (table = the 4 scores of this step's reference symbol per pair, one dword each, from a
+//     (msize + 1)-entry LDS table; selector = the lane's query letters, one VGPR per row).  LDS per wave drops from ~15 KB to
+//     ~3 KB, so the VGPR count alone decides the occupancy.  A selector byte can only pick a table byte or the constants 0x00 /
+//     0xFF, which cannot express the virtual rows of the bottom-aligned layout for a free reference begin: the PT form is
+//     TOP-aligned -- the row above lane 0 is the closed form anyway, padding rows below the query score -open and feed nothing
+//     -- and reads the query's last row (corner, last-row maximum) from register (qlen - 1) % R of lane (qlen - 1) / R with one
+//     indexed move.  That index must be wave-uniform, and a query wildcard has no selector: a block whose pairs differ in query
+//     length or hold a letter beyond the first four marks itself in `blockflag` and leaves; the launcher then runs the LDS-
+//     profile form over exactly the marked blocks (`only_flagged`), and the walk reads the alignment of a block's rows from the
+//     same flags.
+template <int G, int R, bool TR, bool FETCH = false, bool TRB = false, bool PT = false>
+__global__ __launch_bounds__(64, (PT && R <= 20) ? 4 : 1)
 void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                         const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
                         long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
@@ -412,11 +423,14 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
                         int col_pen, int row_pen, int s1_end, int s2_end, int nb,
                         const unsigned *__restrict__ perm,
                         pmx_record_t *__restrict__ out, uint32_t *__restrict__ tbuf, int Tmax,
-                        int track8 /* width 8: report whether some H (boundaries included) leaves [-128, 127] */)
+                        int track8 /* width 8: report whether some H (boundaries included) leaves [-128, 127] */,
+                        int *__restrict__ blockflag /* PT: 1 = this block is left to the LDS-profile form */,
+                        const int *__restrict__ only_flagged /* LDS-profile form behind a PT launch: only the blocks marked there */)
 {
     static_assert(!TR || R == 16, "trace: four packed planes of 4 rows");
+    if (!PT && only_flagged && only_flagged[blockIdx.x] == 0) return;
     constexpr int RS = (R + 3) / 4 * 4;      // profile bytes reserved per lane (whole dwords)
-    constexpr int QP = G * R;                // logical rows (query bottom-aligned in them)
+    constexpr int QP = G * R;                // logical rows (query bottom-aligned in them; PT: top-aligned)
     constexpr int QPS = G * RS;              // profile bytes per (pair, symbol)
     constexpr int SLOTS = 64 / G;
     constexpr int NP = 2 * SLOTS;
@@ -427,12 +441,23 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     const int g = IL ? (lane % 16) / 2 : lane % G;
     const int slot = IL ? (lane / 16) * 2 + (lane & 1) : lane / G;
     const int MS1 = msize + 1;                      // + the pad-symbol row
-    const int PROF_STRIDE = MS1 * QPS;
+    const int PROF_STRIDE = PT ? 0 : MS1 * QPS;
 
     unsigned char *rsym = lds + NP * PROF_STRIDE;
     int16_t *mat = reinterpret_cast<int16_t *>(rsym + (FETCH ? 0 : NP * RP));
     unsigned char *map = reinterpret_cast<unsigned char *>(mat + msize * msize);
     long long *ptab = reinterpret_cast<long long *>(map + 256 + ((8 - ((msize * msize * 2) & 7)) & 7));
+    int *tabs = reinterpret_cast<int *>(ptab + 5 * NP);      // PT: per reference symbol the 4 query-letter scores (+ open); entry msize = the pad symbol
+    constexpr int QS = (G * R + 3) / 4 * 4;
+    unsigned char *qsym = reinterpret_cast<unsigned char *>(tabs + 40);   // PT: mapped query letters, QS bytes per pair (0xFF below the query)
+    // PT + TR: the LDS the profiles no longer take holds eight steps of every lane's trace records, which then leave as ONE aligned
+    // 128-byte line per lane stream, eight lanes per line (pmx_nwsg16q_kernel's flush).  Two steps per 32-byte sector straight from
+    // registers (the LDS-profile form) leave every line of every resident lane stream partly written in the L2 for eight steps --
+    // more lines than the L2s hold: that form's sweep is bound by its write path, not by its instructions (a fourth wave per SIMD
+    // bought it nothing).
+    constexpr bool STG = PT && TR;
+    constexpr int TSTG = 8, TSTR = TSTG * 4 + 1;             // steps per flush; dwords per lane (odd: a step's stores of the lanes fall into different banks)
+    uint32_t *tstage = reinterpret_cast<uint32_t *>(qsym + NP * QS + 16) + (STG ? lane * TSTR : 0);
 
     const long long pair0 = (long long)blockIdx.x * NP;
     for (int i = lane; i < msize * msize; i += 64) mat[i] = gmat[i];
@@ -448,12 +473,49 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         ptab[5 * lane + 4] = (pair0 + lane < n) ? pi : -1;
     }
     __syncthreads();
+    constexpr int UB = NP < 8 ? NP : 8;
+    int qlu = 0;                                             // PT: the block's common query length
+    if (PT) {
+        // the block's eligibility: one query length, no letter beyond the first four (decided before anything else is staged)
+        qlu = (int)ptab[1];
+        bool ok = true;
+#pragma unroll
+        for (int p = 1; p < NP; ++p) ok = ok && (int)ptab[5 * p + 1] == qlu;
+        int wild = 0;
+        for (int p0 = 0; p0 < NP; p0 += UB) {
+            for (int j0 = 0; j0 < QS; j0 += 64) {
+                const int j = j0 + lane;
+                unsigned char raw[UB]; bool in[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    in[u] = j < (int)ptab[5 * (p0 + u) + 1];
+                    raw[u] = in[u] ? qbuf[ptab[5 * (p0 + u) + 0] + j] : (unsigned char)0;
+                }
+                if (j < QS) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int c = in[u] ? (int)map[raw[u]] : 0xFF;
+                        wild |= (c >= 4 && c != 0xFF) ? 1 : 0;
+                        qsym[(p0 + u) * QS + j] = (unsigned char)c;
+                    }
+                }
+            }
+        }
+        ok = ok && __builtin_amdgcn_ballot_w64(wild != 0) == 0 && qlu <= QP;
+        if (lane == 0) blockflag[blockIdx.x] = ok ? 0 : 1;
+        if (!ok) return;                                     // (wave-uniform)
+        if (lane <= msize) {
+            int v = 0;
+            if (lane < msize) { for (int k = 0; k < 4 && k < msize; ++k) v |= ((mat[k * msize + lane] + open) & 0xFF) << (8 * k); }
+            else v = (col_pen ? 0 : open) * 0x01010101;      // real row x virtual / padding column
+            tabs[lane] = v;
+        }
+    }
 
     // ---- reference symbols (pairs in batches of UB, lanes over positions: no division, UB loads in flight)
     int max_rlen = 0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) max_rlen = max(max_rlen, (int)ptab[5 * p + 3]);
-    constexpr int UB = NP < 8 ? NP : 8;
     for (int p0 = 0; p0 < (FETCH ? 0 : NP); p0 += UB) {
         for (int j0 = 0; j0 < RP; j0 += 64) {
             const int j = j0 + lane, jr = j - (G - 1);
@@ -474,7 +536,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     // ---- byte profiles: logical row er = l * R + k sits at byte l * RS + k; P virtual rows on top
     const int vrow_b = row_pen ? 0 : open;         // virtual row x real symbol
     const int vcol_b = col_pen ? 0 : open;         // real row    x pad symbol
-    for (int p0 = 0; p0 < NP; p0 += UB) {
+    for (int p0 = 0; p0 < (PT ? 0 : NP); p0 += UB) {
         for (int e0 = 0; e0 < QP; e0 += 64) {
             const int er = e0 + lane;
             unsigned char raw[UB]; bool real[UB];
@@ -511,19 +573,33 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     const unsigned char *rsA = rsym + pA * RP + (G - 1) - g;
     const unsigned char *rsB = rsym + pB * RP + (G - 1) - g;
 
-    const int PvA = QP - (int)ptab[5 * pA + 1], PvB = QP - (int)ptab[5 * pB + 1];
+    const int PvA = PT ? 0 : QP - (int)ptab[5 * pA + 1], PvB = PT ? 0 : QP - (int)ptab[5 * pB + 1];
     const int rlA = (int)ptab[5 * pA + 3], rlB = (int)ptab[5 * pB + 3];
+    // PT: per-row selectors (byte 0: pair A's letter -> table A = v_perm source bytes 0..3, byte 2: 4 + pair B's letter -> table B =
+    // bytes 4..7, bytes 1 and 3: the constant 0; rows below the query select the constant 0 = score -open, and feed nothing)
+    int sel[PT ? R : 1];
+    const int gs = PT ? (qlu - 1) / R : G - 1, ks = PT ? (qlu - 1) % R : R - 1;       // lane and register of the query's last row
+    if (PT) {
+        const unsigned char *qa = qsym + pA * QS + g * R, *qb_ = qa + QS;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int ca = qa[k], cb = qb_[k];
+            sel[k] = (ca < 4 ? ca : 0x0C) | 0x0C00 | ((cb < 4 ? 4 + cb : 0x0C) << 16) | 0x0C000000;
+        }
+    }
     auto pack2 = [](int a, int b) -> int { return (a & 0xFFFF) | (b << 16); };
     const int vExt = pack2(ext, ext), vC = pack2(open - ext, open - ext);
     const v2us one2 = {1, 1};
     const int base = nb + (G - g) * ext - open;    // X-form of a true 0 in this lane's column j0 - 1 (and E~ of column j0)
 
     auto left_h = [&](int erow, int P) -> int {    // true H(row, virtual column)
-        const int i = erow - P;
+        int i = erow - P;
+        if (PT) i = min(i, qlu - 1);               // (padding rows below the query: any value inside the proven window)
         return (i >= 0 && col_pen) ? -(open + i * ext) : 0;
     };
     auto below_f = [&](int erow, int P) -> int {   // true F flowing into row erow at a virtual column
-        const int i = erow - P;
+        int i = erow - P;
+        if (PT) i = min(i, qlu - 1);
         return (i >= 0 && col_pen) ? -(open + i * ext) : -open;
     };
 
@@ -554,6 +630,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     v2s runmax = PK(HA[0] + vExt), runmin = runmax;    // a boundary value of this lane's row (HA: form of column j0 - 1), in the form of its first column j0
 
     auto load_scores = [&](int symA, int symB, int (&wa)[RS / 4], int (&wb)[RS / 4]) {
+        if (PT) { wa[0] = tabs[symA]; wb[0] = tabs[symB]; return; }
         const int *sa = reinterpret_cast<const int *>(profA + symA * QPS);
         const int *sb = reinterpret_cast<const int *>(profB + symB * QPS);
 #pragma unroll
@@ -583,7 +660,8 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const int s = __builtin_amdgcn_perm(wb[k / 4], wa[k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16));
+            const int s = PT ? __builtin_amdgcn_perm(wb[0], wa[0], (unsigned)sel[k])
+                             : __builtin_amdgcn_perm(wb[k / 4], wa[k / 4], 0x0C000C00u | (unsigned)(k & 3) | ((4u + (unsigned)(k & 3)) << 16));
             Tpre[k] = ((k == 0) ? diag0 : Hold[k - 1]) + s;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -629,7 +707,8 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             // two steps leave together: 32 contiguous bytes per lane = one whole sector (single 16-byte stores of thousands of
             // resident lanes reach HBM as partly written sectors: PMC WRITE_SIZE was 1.7x the bytes stored; four steps per group
             // cost more registers than they save: 26.6 ms against 25.6 ms per cfg-4 step)
-            if (t & 1) { uint4 *dst = reinterpret_cast<uint4 *>(tw + (size_t)(t - 1) * t_ss); dst[0] = wprev; dst[1] = w; }
+            if (STG) { uint32_t *dst = tstage + (t & (TSTG - 1)) * 4; dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w; }
+            else if (t & 1) { uint4 *dst = reinterpret_cast<uint4 *>(tw + (size_t)(t - 1) * t_ss); dst[0] = wprev; dst[1] = w; }
             else wprev = w;
         }
         diag0 = Hin;
@@ -652,9 +731,26 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             runmax = PK(I32(runmax) + vExt); runmin = PK(I32(runmin) + vExt);      // into the next column's skew
         }
         const int mLast = m_eq(jv, rl1);                  // this lane is at column rlen-1
-        res = n_bfi(mLast, Hout, res);
+        // H of the query's last row, where this lane holds it.  PT: a wave-uniform register index -- one indexed move for strips of
+        // up to 16 registers; longer strips (the allocator would move them to scratch for it) pick the register by a select chain in
+        // the rare step that captures the corner, and leave batches that need the last row in every step to the LDS-profile form
+        int Hlast = Hout;
+        if (PT && R <= 16) Hlast = Hnew[ks];
+        if (PT && R > 16) {
+            if (__builtin_amdgcn_ballot_w64(mLast != 0) != 0) {
+                int hl = Hnew[0];
+#pragma unroll
+                for (int k = 1; k < R; ++k) hl = (ks == k) ? Hnew[k] : hl;
+                res = n_bfi(mLast, hl, res);
+            }
+        } else res = n_bfi(mLast, Hlast, res);
         if (s2_end) {
-            const v2s cand = PK(I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, Hout) - __builtin_bit_cast(v2us, skewX))));   // nb + true H
+            if (PT && R > 16) {                           // the last row in every step from a long strip: a select chain (one per row; the
+                Hlast = Hnew[0];                          //  perm-table form's occupancy is worth several times that)
+#pragma unroll
+                for (int k = 1; k < R; ++k) Hlast = (ks == k) ? Hnew[k] : Hlast;
+            }
+            const v2s cand = PK(I32(__builtin_bit_cast(v2s, __builtin_bit_cast(v2us, Hlast) - __builtin_bit_cast(v2us, skewX))));   // nb + true H
             const int imp = m_lt(bestrow, cand) & m_ult(jv, rlv);
             bestrow = PK(n_bfi(imp, I32(cand), I32(bestrow)));
             bestrowj = n_bfi(imp, jj, bestrowj);
@@ -666,7 +762,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int er = g * R + k;
-                const int mreal = ~m_lt(PK(pack2(er, er)), Pv);
+                const int mreal = PT ? (er < qlu ? -1 : 0) : ~m_lt(PK(pack2(er, er)), Pv);
                 vals[k] = PK(Hnew[k] & mreal);
                 cm = n_max3f(cm, vals[k], vals[k]);
             }
@@ -716,6 +812,18 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         __builtin_amdgcn_sched_barrier(0);
         step(HB, HA, w1a, w1b, t + 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (STG && ((t & (TSTG - 2)) == (TSTG - 2) || t + 2 >= T)) {             // eight steps gathered (or the sweep ends)
+            // item w of the flush = 16-byte piece w % 8 of lane stream w / 8: every store instruction writes whole 128-byte lines
+            const uint32_t *wstage = tstage - lane * TSTR;                          // the wave's staging area
+            uint32_t *wtw = tw - (size_t)lane * Tmax * 4;                           // the wave's lane stream 0
+#pragma unroll
+            for (int x = 0; x < TSTG; ++x) {
+                const int w = x * 64 + lane, stream = w >> 3, piece = w & 7;
+                const uint32_t *src = wstage + stream * TSTR + piece * 4;
+                uint4 v; v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+                *reinterpret_cast<uint4 *>(wtw + ((size_t)stream * Tmax + (size_t)(t & ~(TSTG - 1))) * 4 + piece * 4) = v;
+            }
+        }
     }
 
     // ---- combine (all captured values -> true scores) ---------------------------------------
@@ -728,7 +836,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         keyA = oa > keyA ? oa : keyA;
         keyB = ob > keyB ? ob : keyB;
     }
-    const int lastlane = IL ? 2 * (G - 1) + (slot & 1) + 16 * (slot >> 1) : slot * G + G - 1;
+    const int lastlane = IL ? 2 * gs + (slot & 1) + 16 * (slot >> 1) : slot * G + gs;       // the lane that holds the query's last row
     const int resL = __shfl(res, lastlane, 64);
     const int browL = __shfl(I32(bestrow), lastlane, 64), browjL = __shfl(bestrowj, lastlane, 64);
     int hiA = 0, hiB = 0, loA = 0, loB = 0;                // width 8: true extremes of H over the group's cells (0 = H(-1, -1) counts)
@@ -749,7 +857,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             const long long pi = ptab[5 * (2 * slot + h) + 4];
             if (pi >= 0) {
                 const int ql = (int)ptab[5 * (2 * slot + h) + 1], rl = (int)ptab[5 * (2 * slot + h) + 3];
-                const int P = QP - ql;
+                const int P = PT ? 0 : QP - ql;
                 const int unsk = nb + (rl - 1 + G) * ext - open + ext;          // X-form of a true 0 at column rlen-1
                 const int corner = (int)(h ? ((unsigned)resL >> 16) : (resL & 0xFFFF)) - unsk;
                 pmx_record_t rec;
@@ -1440,6 +1548,10 @@ static int launch_nwsg(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
     return e == hipSuccess ? 0 : -(int)e;
 }
 
+static thread_local bool g_nwsgv_pt = false;          // the last launch_nwsgv of this thread ran the perm-table form first (kernel names)
+// PTOK: the shape has a perm-table instantiation (the ones BASELINE-sized DNA batches take; every instantiation costs compile time)
+template <int G, int R, bool TR> struct NwsgPtShape { static constexpr bool value = (!TR && G == 8 && (R == 10 || R == 13 || R == 16 || R == 19)) || (G == 16 && R == 16); };
+
 template <int G, int R, bool TR = false, bool FETCH = false, bool TRB = false>
 static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
                         pmx_record_t *d_out, hipStream_t stream, uint32_t *tbuf = nullptr, int Tmax = 0)
@@ -1457,10 +1569,33 @@ static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
+    // Alphabets of <= 4 letters (+ wildcard): the perm-table form first (no LDS profile: see PT at the kernel); it marks the blocks
+    // it cannot take -- query lengths that differ inside the block, a query letter beyond the first four -- and the LDS-profile form
+    // below then runs over exactly those.  Needs the caller's per-block flags (PmxBatch::blockflag).
+    const int *only = nullptr;
+    g_nwsgv_pt = false;
+    if constexpr (NwsgPtShape<G, R, TR>::value && !FETCH && (!TR || TRB)) {
+        if (m.msize <= 5 && b.blockflag && !b.track8 && !b.q_shared && !pmx_env("PMX_NWSG16_NO_PERMTABLE")) {
+            const size_t lds_pt = (size_t)NP * RP + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40 + 160 + (size_t)NP * ((G * R + 3) / 4 * 4) + 32 +
+                                  (TR ? (size_t)64 * 33 * 4 : 0);
+            hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, false, TRB, true>), dim3((unsigned)blocks), dim3(64), lds_pt, stream,
+                               b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
+                               m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax,
+                               0, b.blockflag, (const int *)nullptr);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return -(int)e;
+            only = b.blockflag;
+            g_nwsgv_pt = true;
+        }
+    }
+    if (!only && b.blockflag) {                             // every block bottom-aligned: the walk reads the flags
+        const hipError_t e = hipMemsetAsync(b.blockflag, 0xFF, (size_t)blocks * sizeof(int), stream);
+        if (e != hipSuccess) return -(int)e;
+    }
     hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, FETCH, TRB>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                        m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax,
-                       TR ? 0 : b.track8);
+                       TR ? 0 : b.track8, (int *)nullptr, only);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
@@ -1572,7 +1707,7 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
         if (q <= (GG) * (RR)) {                                             \
             int rc = longref ? launch_nwsgv<GG, RR, false, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream) \
                              : launch_nwsgv<GG, RR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream); \
-            if (rc <= 0) { if (kernel_name) *kernel_name = longref ? NAME "/fetch" : NAME; return rc; }   \
+            if (rc <= 0) { if (kernel_name) *kernel_name = longref ? NAME "/fetch" : g_nwsgv_pt ? NAME "/permtable (+ LDS profiles for marked blocks)" : NAME; return rc; }   \
         }
         if (b.n > 2048) {       // (few pairs: latency counts, the 16-lane shapes have half the work per step)
             TRYV(8, 7, "pmx_nwsg16v_kernel<8,7>")        // reads of 50 / 75 / 100 / 125 / 150 bp: few padding rows

@@ -24,6 +24,7 @@ struct PmxSwitchDoc { const char *name, *kind, *what; };
     X("PMX_SW16_NO_FETCH",            "force", "local, references >= 1024: stage references in LDS instead of fetching them two steps ahead") \
     X("PMX_NO_FAST_NWSG",             "force", "global / semi-global: general int32 kernel instead of the packed int16 kernels") \
     X("PMX_NWSG8_GENERAL",            "force", "global / semi-global at width 8: general int32 kernel instead of the packed int16 kernel with range tracking") \
+    X("PMX_NWSG16_NO_PERMTABLE",      "force", "global / semi-global, alphabets of <= 4 letters: LDS profiles instead of the v_perm score table (top-aligned form)") \
     X("PMX_NWSG16_GEN1",              "force", "global / semi-global: first-generation packed kernel") \
     X("PMX_NWSG16_NO_SHARED",         "force", "global / semi-global, profile arm: per-pair profiles instead of the shared-profile kernel") \
     X("PMX_NWSG16_NO_MATRIX_LOOKUP",  "force", "global / semi-global, large alphabets: LDS profiles instead of the matrix-lookup kernel") \

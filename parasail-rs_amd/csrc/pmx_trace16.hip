@@ -527,7 +527,8 @@ int pmx_launch_trace16(int variant, const PmxBatch &b, const PmxDevMatrix &m, in
         int32_t *textlen = split ? split->textlen : nullptr;
         // (Tmax is a multiple of 16 -- the plans round it -- so a walk window never crosses into the next lane's stream)
         rc = pmx_launch_walkp((variant % 10) & 3, 16, b, m, mode, open, ext, Tmax, top, stats_out, row_pen_, col_pen_,
-                              (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, ops_base, nops, beg, textlen, wstream);
+                              (const uint32_t *)tbuf, (const pmx_record_t *)d_out, ops, ops_off, ops_base, nops, beg, textlen, wstream,
+                              (!top && variant - 10 < 4) ? b.blockflag : nullptr);      // (the nwsgv shapes: their launcher fills the flags)
         if (rc) return rc;
         hipError_t e = hipGetLastError();
         if (e == hipSuccess && split && split->walk_done) e = hipEventRecord(split->walk_done, wstream);

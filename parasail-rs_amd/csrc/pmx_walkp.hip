@@ -33,7 +33,7 @@ void pmx_walkp_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
                       const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
                       long long n, const unsigned *__restrict__ perm,
                       const uint8_t *__restrict__ mapper, const int16_t *__restrict__ scores, int msize, int open, int ext,
-                      int mode, int Tmax, int top_aligned,
+                      int mode, int Tmax, int top_aligned, const int *__restrict__ blockflag /* per sweep block: 0 = its rows are top-aligned */,
                       pmx_stats_t *__restrict__ stats_out, int row_pen, int col_pen,
                       const uint32_t *__restrict__ tbuf, const pmx_record_t *__restrict__ recs,
                       uint32_t *__restrict__ ops, const int64_t *__restrict__ ops_off, long long ops_base,
@@ -58,7 +58,7 @@ void pmx_walkp_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
     const uint8_t *q = qbuf + qb, *r = rbuf + rb;
     const long long area = pos / NPW; const int slot = (int)(pos % NPW);
     const uint32_t *tb = tbuf + (size_t)area * Tmax * (64 * D);
-    const int P = top_aligned ? 0 : QP - ql;
+    const int P = (top_aligned || (blockflag && blockflag[area] == 0)) ? 0 : QP - ql;
     const bool st = stats_out != nullptr;
     const bool sw = mode == PMX_MODE_SW;
     const long long slot_lo = ops_off ? ops_off[pair] : qb + rb + pair - ops_base;
@@ -185,12 +185,12 @@ void pmx_walkp_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
 int pmx_launch_walkp(int gsel, int R, const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext, int Tmax, int top_aligned,
                      pmx_stats_t *stats_out, int row_pen, int col_pen, const uint32_t *tbuf, const pmx_record_t *recs,
                      uint32_t *ops, const int64_t *ops_off, long long ops_base, int32_t *nops, int32_t *beg, int32_t *textlen,
-                     hipStream_t stream)
+                     hipStream_t stream, const int *blockflag)
 {
     if (b.n <= 0) return 0;
     const dim3 grid((unsigned)((b.n * LG + 255) / 256)), block(256);
 #define WALKP(GG, RR) hipLaunchKernelGGL((pmx_walkp_kernel<GG, RR>), grid, block, 0, stream, \
-        b.qbuf, b.qoff, b.q_shared, b.rbuf, b.roff, (long long)b.n, b.perm, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, top_aligned, \
+        b.qbuf, b.qoff, b.q_shared, b.rbuf, b.roff, (long long)b.n, b.perm, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, top_aligned, blockflag, \
         stats_out, row_pen, col_pen, tbuf, recs, ops, ops_off, ops_base, nops, beg, textlen)
     if (R == 16) {
         switch (gsel) {

@@ -1438,3 +1438,63 @@ def test_fuzz_local_end_cells_any_scoring(pkg, orc, seed):
         want = orc.align_batch(orc.SW, qb, qo, rb, ro, open_, ext, om)
         bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
         assert len(bad) == 0, (seed, it, match, mism, open_, ext, uniform, L, pkg.lib.pmx_last_kernel().decode(), bad[:5], got[bad[:5]], want[bad[:5]])
+
+
+# --------------------------------------------------- perm-table (top-aligned) form of the global / semi-global kernels ----
+@pytest.mark.parametrize("mode,sg", [(0, None), (1, None), (1, 1 | 8), (1, 2 | 4), (1, 2), (1, 8)])
+@pytest.mark.parametrize("L", [75, 100, 125, 150, 250])
+def test_nwsg16_permtable_form_uniform_reads(pkg, orc, mode, sg, L):
+    """Equal-length DNA reads (the common case of a read set): global / semi-global scores without an LDS profile -- the v_perm
+    looks the score up, rows top-aligned -- every free-end variant against the oracle; blocks that hold a query with a letter
+    beyond the first four, or queries of different lengths, fall to the LDS-profile form inside the same call."""
+    rng = np.random.default_rng(4400 + L + mode)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    n = 4300
+    qs = random_seqs(rng, n, L, L)
+    rs = [mutate(rng, q, 0.1, 0.03) if k % 3 else random_seqs(rng, 1, L - 20, L + 30)[0] for k, q in enumerate(qs)]
+    qs[7] = qs[7][:L // 2] + b"N" + qs[7][L // 2 + 1:]            # a wildcard in one query: its block takes the LDS-profile form
+    qs[100] = qs[100][:L - 9]                                    # a shorter query: likewise
+    qs[3000] = qs[3000].lower()
+    b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).solution_width(16)
+    [b.global_, b.semi_global][mode]()
+    if sg is not None:
+        b.allow_query_gaps([n_ for f, n_ in ((1, "prefix"), (2, "suffix")) if sg & f]).allow_ref_gaps([n_ for f, n_ in ((4, "prefix"), (8, "suffix")) if sg & f])
+    got = b.build().align_batch(qs, rs)
+    kernel = pkg.lib.pmx_last_kernel().decode()
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    want = orc.align_batch(mode, qb, qo, rb, ro, 5, 2, om, sg_flags=sg if sg is not None else orc.SG_ALL)
+    bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
+    assert len(bad) == 0, (mode, sg, L, kernel, bad[:8], got[bad[:4]], want[bad[:4]])
+    assert (got["flags"] == 0).all()
+    if L <= 152:
+        assert "permtable" in kernel, kernel
+
+
+def test_nwsg16_permtable_form_with_traceback_and_statistics(pkg, orc):
+    """the traceback sweeps' perm-table form: CIGAR text and statistics of equal-length reads (BASELINE config 4's shape), with
+    blocks that fall to the LDS-profile form mixed in; the walk reads every block's row alignment from the sweep's flags"""
+    rng = np.random.default_rng(4500)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    n = 3000
+    for L in (250, 120):
+        qs = random_seqs(rng, n, L, L)
+        rs = [mutate(rng, q, 0.1, 0.03)[:L + 10] for q in qs]
+        qs[5] = qs[5][:40] + b"N" + qs[5][41:]
+        qs[1000] = qs[1000][:L - 31]
+        qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+        idx = np.unique(np.concatenate([np.arange(0, n, 13), [5, 6, 7, 1000, 1001, 2999]]))
+        for mode in (1, 0):
+            b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).solution_width(16)
+            [b.global_, b.semi_global][mode]()
+            rec, text, coff = b.use_trace().build().align_batch_cigar_packed(qb, qo, rb, ro)
+            want_text, want = orc.cigar_sample(mode, idx, qb, qo, rb, ro, 5, 2, om)
+            raw = text.tobytes()
+            for t, k in enumerate(idx):
+                assert (rec["score"][k], rec["end_query"][k], rec["end_ref"][k]) == tuple(want[t, :3]), (L, mode, k)
+                assert raw[coff[k]:coff[k + 1]].decode() == want_text[t], (L, mode, k)
+            b2 = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).solution_width(16)
+            [b2.global_, b2.semi_global][mode]()
+            r2, st = b2.use_stats().build().align_batch_packed(qb, qo, rb, ro)
+            ws = orc.align_stats_sample(mode, idx, qb, qo, rb, ro, 5, 2, om)
+            got = np.stack([r2["score"][idx], r2["end_query"][idx], r2["end_ref"][idx], st["matches"][idx], st["similar"][idx], st["length"][idx]], axis=1)
+            assert (got == ws[:, :6]).all(), (L, mode)
