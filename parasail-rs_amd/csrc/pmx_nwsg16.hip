@@ -415,7 +415,7 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
 //     profile form over exactly the marked blocks (`only_flagged`), and the walk reads the alignment of a block's rows from the
 //     same flags.
 template <int G, int R, bool TR, bool FETCH = false, bool TRB = false, bool PT = false>
-__global__ __launch_bounds__(64, (PT && R <= 20) ? 4 : 1)
+__global__ __launch_bounds__(64, (PT && !TR && R <= 20) ? 4 : (PT && TR) ? 3 : 1)      // (PT + TR: the staged records' LDS allows 2.75 waves per SIMD)
 void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                         const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
                         long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
@@ -1550,7 +1550,10 @@ static int launch_nwsg(const PmxBatch &b, const PmxDevMatrix &m, int mode, int s
 
 static thread_local bool g_nwsgv_pt = false;          // the last launch_nwsgv of this thread ran the perm-table form first (kernel names)
 // PTOK: the shape has a perm-table instantiation (the ones BASELINE-sized DNA batches take; every instantiation costs compile time)
-template <int G, int R, bool TR> struct NwsgPtShape { static constexpr bool value = (!TR && G == 8 && (R == 10 || R == 13 || R == 16 || R == 19)) || (G == 16 && R == 16); };
+template <int G, int R, bool TR> struct NwsgPtShape {
+    static constexpr bool value = (!TR && G == 8 && (R == 7 || R == 10 || R == 13 || R == 16 || R == 19 || R == 20)) || (G == 16 && R == 16) ||
+                                  (!TR && G == 32 && R == 16);
+};
 
 template <int G, int R, bool TR = false, bool FETCH = false, bool TRB = false>
 static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
