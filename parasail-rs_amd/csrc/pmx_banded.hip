@@ -390,6 +390,209 @@ void pmx_banded_staged_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Third form (round 3): LOCAL alignment, two pairs per lane group in the int16 halves of every register, the lean loop only.
+//
+// The staged kernel above spends 17 instructions per cell in its interior loop and ~140 in the checked steps at the matrix edges.
+// For local alignment the edges need no checking at all: a cell outside the matrix that computes on PAD symbols (score -open
+// against everything) floors to 0 like the boundary it stands for, feeds nothing real (dependencies run down and right) and can
+// never strictly exceed a real cell (its value reaches it through a gap) -- so both sequences are staged with pad margins on
+// both sides and EVERY step runs the lean form.  Values are biased (true 0 = B, B = 1024 + open + extend: every live value is
+// 0 or in [1024, 31743], where v_pk_maximum3_f16 is an exact integer max3 and v_pk_sub_u16 with clamp keeps "minus infinity" = 0
+// sticky); the strips carry H - open and the scores carry + open, so the diagonal sum is one add; the zero floor is folded into
+// E.  A lane keeps its best and the step where it was first strictly exceeded (per half); cell (i, j) follows from the step.
+// 15.5 instructions per TWO cells.  The host proves the range (score bound + B < 31744, min score + open >= 0).
+typedef short b_v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short b_v2us __attribute__((ext_vector_type(2)));
+typedef _Float16 b_v2h __attribute__((ext_vector_type(2)));
+#define BPK(x) __builtin_bit_cast(b_v2s, (int)(x))
+#define BI32(x) __builtin_bit_cast(int, (x))
+__device__ __forceinline__ int bp_max3(int a, int b, int c)
+{
+    const b_v2h r = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(b_v2h, a), __builtin_bit_cast(b_v2h, b)),
+                                                  __builtin_bit_cast(b_v2h, c));
+    return __builtin_bit_cast(int, r);
+}
+__device__ __forceinline__ int bp_subus(int a, int b)         // v_pk_sub_u16 clamp: saturates at 0
+{
+    return __builtin_bit_cast(int, __builtin_elementwise_sub_sat(__builtin_bit_cast(b_v2us, a), __builtin_bit_cast(b_v2us, b)));
+}
+
+template <int LP>
+__global__ __launch_bounds__(64)
+void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff, int q_shared,
+                              const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff, long long n,
+                              const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap, int msize,
+                              int open, int ext, int band, const int32_t *__restrict__ diag,
+                              int QC, int RC /* staging capacity per pair, margins included */, pmx_record_t *__restrict__ out)
+{
+    constexpr int MG = 160;                                  // pad symbols in front of and behind every staged sequence
+    __shared__ unsigned char matp[(PMX_MAX_FAST_MSIZE + 1) * (PMX_MAX_FAST_MSIZE + 1)];    // score + open as a byte; row / column msize = the pad symbol
+    __shared__ unsigned char map[256];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    const int MS1 = msize + 1;
+    for (int x = threadIdx.x; x < MS1 * MS1; x += 64) {
+        const int a = x / MS1, b = x - a * MS1;
+        matp[x] = (a < msize && b < msize) ? (unsigned char)(gmat[a * msize + b] + open) : (unsigned char)0;      // pad: score -open
+    }
+    for (int x = threadIdx.x; x < 256; x += 64) map[x] = gmap[x];
+    __syncthreads();
+
+    constexpr int NG = 64 / LP, NPW = 2 * NG;                // lane groups, pairs per wave
+    const int lane = threadIdx.x, x = lane % LP, grp = lane / LP;
+    // per half: geometry of the pair
+    long long pairH[2]; bool haveH[2]; int qlH[2], rlH[2], d0H[2], I0H[2], J0H[2], nstH[2]; bool hitH[2];
+    int nsteps = 0;
+    unsigned short *qm_all = reinterpret_cast<unsigned short *>(dyn);            // [NPW][QC]: symbol * MS1, 16 bits
+    unsigned char *rm_all = dyn + (size_t)NPW * QC * 2;                           // [NPW][RC]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const long long pair = (long long)blockIdx.x * NPW + 2 * grp + h;
+        pairH[h] = pair; haveH[h] = pair < n;
+        const long long pp = haveH[h] ? pair : n - 1;
+        const long long qb = q_shared ? 0 : qoff[pp], rb = roff[pp];
+        const int ql = min(q_shared ? q_shared : (int)(qoff[pp + 1] - qb), QC - 2 * MG), rl = min((int)(roff[pp + 1] - rb), RC - 2 * MG);
+        qlH[h] = ql; rlH[h] = rl;
+        const int d0 = diag ? diag[pp] : 0;
+        d0H[h] = d0;
+        const int dlo = d0 - band, dhi = d0 + band;
+        int s_first = 0;
+        if (dlo > 0) s_first = dlo; else if (dhi < 0) s_first = -dhi;
+        int s_last = -1;
+        {
+            int i1 = ql - 1, j1 = rl - 1;
+            if (j1 - i1 > dhi) j1 = i1 + dhi; else if (j1 - i1 < dlo) i1 = j1 - dlo;
+            if (i1 >= 0 && j1 >= 0 && haveH[h]) s_last = i1 + j1;
+        }
+        if (dlo > rl - 1 || dhi < -(ql - 1)) s_last = -1;
+        hitH[h] = s_last >= 0;
+        // two steps early (same parity): every lane starts on pad cells, whose zeros ARE the boundary the first real cells read
+        const int s0 = s_first - ((s_first + band - d0) & 1) - 2;
+        int ns = s_last - s0 + 1; if (ns < 0 || s_last < 0) ns = 0;
+        nstH[h] = ns;
+        nsteps = max(nsteps, ns);
+        I0H[h] = ((s0 + band - d0) >> 1) - x; J0H[h] = I0H[h] + 2 * x - band + d0;
+        // stage this pair's sequences (all lanes of the wave work on one pair at a time: its offsets come from its group's lane 0)
+#pragma unroll
+        for (int g2 = 0; g2 < NG; ++g2) {
+            const long long qb2 = __shfl(qb, g2 * LP, 64), rb2 = __shfl(rb, g2 * LP, 64);
+            const int ql2 = __shfl(ql, g2 * LP, 64), rl2 = __shfl(rl, g2 * LP, 64);
+            unsigned short *qd = qm_all + (size_t)(2 * g2 + h) * QC;
+            unsigned char *rd = rm_all + (size_t)(2 * g2 + h) * RC;
+            for (int t = lane; t < ql2 + 2 * MG; t += 64) {
+                const int i = t - MG;
+                qd[t] = (unsigned short)(((i >= 0 && i < ql2) ? (int)map[qbuf[qb2 + i]] : msize) * MS1);
+            }
+            for (int t = lane; t < rl2 + 2 * MG; t += 64) {
+                const int j = t - MG;
+                rd[t] = (unsigned char)((j >= 0 && j < rl2) ? (int)map[rbuf[rb2 + j]] : msize);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, off, 64));
+    nsteps = (nsteps + 7) & ~7;
+    __syncthreads();
+
+    const int B = 1024 + open + ext;                          // true 0
+    const int B2 = B * 0x00010001, vOpen = open * 0x00010001, vExt = ext * 0x00010001;
+    const int keep_odd = x >= band ? 0 : -1;                  // the lane's odd diagonal lies outside the band: forced to "minus infinity"
+    const int floorv = x <= band ? B2 : 0;                    // zero floor only inside the band
+    const int first_ok = x == 0 ? 0 : -1, last_ok = x == LP - 1 ? 0 : -1;
+    auto below = [&](int v) -> int {                          // value of lane x - 1, 0 ("minus infinity") at the band's first lane
+        int r = __builtin_amdgcn_update_dpp(0, v, LP == 16 ? 0x111 /*row_shr:1*/ : 0x138 /*wave_shr:1*/, 0xF, 0xF, true);
+        if (LP == 32) r &= first_ok;
+        return r;
+    };
+    auto above = [&](int v) -> int {                          // value of lane x + 1, 0 at the group's last lane
+        int r = __builtin_amdgcn_update_dpp(0, v, LP == 16 ? 0x101 /*row_shl:1*/ : 0x130 /*wave_shl:1*/, 0xF, 0xF, true);
+        if (LP == 32) r &= last_ok;
+        return r;
+    };
+    const b_v2s sh15 = {15, 15};
+    // LDS read positions (element indices), clamped into the trailing pad once a pair has run past its sequences
+    int qpos[2], rpos[2], qend[2], rend[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        qpos[h] = I0H[h] + MG; rpos[h] = J0H[h] + MG;
+        qend[h] = qlH[h] + MG + 8; rend[h] = rlH[h] + MG + 8;                     // 8 .. MG pads follow
+        qpos[h] = min(max(qpos[h], 0), qend[h]); rpos[h] = min(max(rpos[h], 0), rend[h]);
+        // lanes beyond the band read pad symbols only: on real symbols their unfloored, unmasked cells could climb along a run of
+        // matches (low-complexity sequences) from "minus infinity" into the range of real values -- B is 1 024, not 2^30
+        if (x > band) { qpos[h] = qend[h]; rpos[h] = rend[h]; }
+    }
+    const unsigned short *qmA = qm_all + (size_t)(2 * grp) * QC, *qmB = qmA + QC;
+    const unsigned char *rmA = rm_all + (size_t)(2 * grp) * RC, *rmB = rmA + RC;
+
+    // state: everything "minus infinity" (0) except nothing -- the pad cells in front of the matrix produce the zero boundary
+    int Ho1 = 0, Ho2 = 0, Ee1 = 0, Fe1 = 0;                   // H - open of the lane's previous cell and of the one before; E - ext; F - ext
+    int bH = B2, bT = 0;                                      // best (only a score above 0 is tracked) and the step where it was first exceeded
+    for (int t0 = 0; t0 < nsteps; t0 += 8) {
+        int sc[8];
+        {
+            int mq[2][4], mr[2][5];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { mq[0][k] = qmA[qpos[0] + k]; mq[1][k] = qmB[qpos[1] + k]; }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { mr[0][k] = rmA[rpos[0] + k]; mr[1][k] = rmB[rpos[1] + k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sc[2 * k] = (int)matp[mq[0][k] + mr[0][k]] | ((int)matp[mq[1][k] + mr[1][k]] << 16);
+                sc[2 * k + 1] = (int)matp[mq[0][k] + mr[0][k + 1]] | ((int)matp[mq[1][k] + mr[1][k + 1]] << 16);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { qpos[h] = min(qpos[h] + 4, qend[h]); rpos[h] = min(rpos[h] + 4, rend[h]); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            {   // even step: left from lane x - 1, up = own previous cell
+                const int lHo = below(Ho1), lEe = below(Ee1);
+                const int E = bp_max3(lEe, lHo, floorv), F = bp_max3(Fe1, Ho1, Ho1);
+                const int H = bp_max3(Ho2 + sc[2 * k], E, F);
+                const int m = BI32((BPK(bH) - BPK(H)) >> sh15);          // 0xFFFF where H > best
+                bH = bp_max3(bH, H, H);
+                bT = (bT & ~m) | (((t0 + 2 * k) * 0x00010001) & m);
+                Ho2 = Ho1; Ho1 = bp_subus(H, vOpen); Ee1 = bp_subus(E, vExt); Fe1 = bp_subus(F, vExt);
+            }
+            {   // odd step: up from lane x + 1, left = own previous cell
+                const int uHo = above(Ho1), uFe = above(Fe1);
+                int E = bp_max3(Ee1, Ho1, floorv), F = bp_max3(uFe, uHo, uHo);
+                int H = bp_max3(Ho2 + sc[2 * k + 1], E, F);
+                H &= keep_odd; E &= keep_odd; F &= keep_odd;
+                const int m = BI32((BPK(bH) - BPK(H)) >> sh15);
+                bH = bp_max3(bH, H, H);
+                bT = (bT & ~m) | (((t0 + 2 * k + 1) * 0x00010001) & m);
+                Ho2 = Ho1; Ho1 = bp_subus(H, vOpen); Ee1 = bp_subus(E, vExt); Fe1 = bp_subus(F, vExt);
+            }
+        }
+    }
+
+    // ---- per half: the lane's candidate, reduced over the group -----------------------------------------------------------
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int hb = h ? (int)((unsigned)bH >> 16) : (bH & 0xFFFF), tb = h ? (int)((unsigned)bT >> 16) : (bT & 0xFFFF);
+        BCand best = {B_NEG, 0, 0};
+        if (hb > B) { best.H = hb - B; best.i = I0H[h] + (tb >> 1); best.j = J0H[h] + (tb >> 1) + (tb & 1); }
+#pragma unroll
+        for (int off = LP / 2; off >= 1; off >>= 1) {
+            BCand o;
+            o.H = __shfl_xor(best.H, off, 64); o.i = __shfl_xor(best.i, off, 64); o.j = __shfl_xor(best.j, off, 64);
+            if (b_better_sw(o, best)) best = o;
+        }
+        if (x == 0 && haveH[h]) {
+            pmx_record_t rec; rec.flags = 0;
+            if (!hitH[h]) { rec.score = B_NEG; rec.end_query = 0; rec.end_ref = 0; }        // the band misses the matrix
+            else if (best.H == B_NEG) {
+                // no cell above 0: the first cell of the band in column-major order (smallest column, then smallest row)
+                const int dlo = d0H[h] - band, dhi = d0H[h] + band;
+                const int j = max(0, dlo), i = max(0, j - dhi);
+                rec.score = 0; rec.end_query = i; rec.end_ref = j;
+            } else { rec.score = best.H; rec.end_query = best.i; rec.end_ref = best.j; }
+            out[pairH[h]] = rec;
+        }
+    }
+}
+
 int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,
                       const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
                       int max_qlen, int max_rlen, int band, const int32_t *diag, pmx_record_t *out, hipStream_t stream,
@@ -405,6 +608,24 @@ int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMat
     const bool staged = !pmx_env("PMX_BANDED_NO_STAGING") && lds <= 60 * 1024 && open <= 512 && ext <= 512 &&
                         (long long)max_qlen + max_rlen < (1 << 20);
     const bool sw = mode == PMX_MODE_SW;
+    // local alignment inside the int16 window: two pairs per lane group, lean loop only (third form above)
+    if (sw && !pmx_env("PMX_BANDED_NO_STAGING") && !pmx_env("PMX_BANDED_NO_PACKED") && open >= 0 && ext >= 0 && open + ext <= 2048 &&
+        m.min + open >= 0 && m.max + open <= 255 && m.msize <= PMX_MAX_FAST_MSIZE - 1 &&
+        (long long)(max_qlen < max_rlen ? max_qlen : max_rlen) * (m.max > 0 ? m.max : 0) + 1024 + open + ext + (m.max > 0 ? m.max : 0) < 31000) {
+        const int LPp = band <= 15 ? 16 : band <= 31 ? 32 : 64, NPWp = 2 * (64 / LPp);
+        const int QCp = ((max_qlen + 2 * 160 + 3) & ~3), RCp = ((max_rlen + 2 * 160 + 3) & ~3);
+        const size_t ldsp = (size_t)NPWp * ((size_t)QCp * 2 + RCp);
+        if (ldsp <= 150 * 1024) {
+#define LPK(LP) do { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_banded_packed_kernel<LP>)); if (rc) return rc; \
+        hipLaunchKernelGGL((pmx_banded_packed_kernel<LP>), dim3((unsigned)((n + NPWp - 1) / NPWp)), dim3(64), ldsp, stream, \
+                           qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, open, ext, band, diag, QCp, RCp, out); } while (0)
+            if (band <= 15) LPK(16); else if (band <= 31) LPK(32); else LPK(64);
+#undef LPK
+            if (kernel_name) *kernel_name = "pmx_banded_packed_kernel";
+            const hipError_t e = hipGetLastError();
+            return e == hipSuccess ? 0 : -(int)e;
+        }
+    }
 #define LB(LP) hipLaunchKernelGGL((pmx_banded_kernel<LP>), dim3((unsigned)((n + 64 / LP - 1) / (64 / LP))), dim3(64), 0, stream, \
                                   qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, mode, sg_flags, open, ext, band, diag, out)
 #define LS(LP, SWF) hipLaunchKernelGGL((pmx_banded_staged_kernel<LP, SWF>), dim3((unsigned)((n + 64 / LP - 1) / (64 / LP))), dim3(64), lds, stream, \

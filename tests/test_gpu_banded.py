@@ -58,7 +58,8 @@ def test_banded_batch_every_mode_with_band_centres(pkg, orc, mode, k, staged, mo
     for dg in (None, diag):
         got = al.align_batch_banded(qs, rs, k, dg)
         kernel = pkg.lib.pmx_last_kernel().decode()
-        assert kernel == ("pmx_general_kernel/banded" if k > 63 else "pmx_banded_staged_kernel" if staged else "pmx_banded_kernel"), kernel
+        assert kernel == ("pmx_general_kernel/banded" if k > 63 else ("pmx_banded_packed_kernel" if mode == 2 else "pmx_banded_staged_kernel") if staged
+                          else "pmx_banded_kernel"), kernel
         want = orc.align_banded_batch(mode, qb, qo, rb, ro, 5, 2, om, k, dg)
         bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
         assert len(bad) == 0, (mode, k, dg is None, bad[:5], got[bad[:3]], want[bad[:3]], [(len(qs[x]), len(rs[x])) for x in bad[:3]])
@@ -92,7 +93,7 @@ def test_cfg5_banded_sw_second_pass(pkg, orc):
     rs = [rbuf[roff[k]:roff[k + 1]].tobytes() for k in range(n)]
     band = 48
     got = al.align_batch_banded([], rs, band, diag)
-    assert pkg.lib.pmx_last_kernel().decode() == "pmx_banded_staged_kernel"
+    assert pkg.lib.pmx_last_kernel().decode() == "pmx_banded_packed_kernel"
     assert (got["score"] <= full["score"]).all()
     assert (got["score"][planted] == full["score"][planted]).all()
     assert (got["end_query"][planted] == full["end_query"][planted]).all() and (got["end_ref"][planted] == full["end_ref"][planted]).all()
@@ -284,3 +285,45 @@ def test_long_single_pairs_share_the_waves_of_a_workgroup(pkg, orc, mode):
     many_q, many_r = qs[:2] * 40, rs[:2] * 40                      # 80 pairs: one wave per pair
     big = al.align_batch(many_q, many_r)
     assert (big["score"][:2] == want[:2, 0]).all() and (big["score"][::2] == want[0, 0]).all() and (big["end_ref"][1::2] == want[1, 2]).all()
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 7, 15, 16, 31, 32, 48, 63])
+def test_banded_local_packed_kernel_edges_and_low_complexity(pkg, orc, k, monkeypatch):
+    """The packed int16 form of banded LOCAL alignment (two pairs per lane group, pad margins instead of edge checks) against the
+    banded oracle AND the 32-bit staged form: one-symbol sequences, bands that miss the matrix or clip a corner, pairs without a
+    single match (score 0: the end cell is the band's first cell in column-major order), an odd pair count, neighbours of very
+    different lengths in one lane group, and low-complexity sequences whose out-of-band diagonals are long runs of matches."""
+    rng = np.random.default_rng(8700 + k)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs, rs, dg = [], [], []
+    for t in range(401):
+        kind = t % 8
+        if kind == 0:
+            q = random_seqs(rng, 1, 1, 200)[0]; r = mutate(rng, q, 0.1, 0.05); d = int(rng.integers(-3, 4))
+        elif kind == 1:
+            q = random_seqs(rng, 1, 1, 3)[0]; r = random_seqs(rng, 1, 1, 300)[0]; d = int(rng.integers(-5, 300))
+        elif kind == 2:
+            q = b"A" * int(rng.integers(1, 300)); r = b"A" * int(rng.integers(1, 300)); d = int(rng.integers(-40, 40))
+        elif kind == 3:
+            q = b"ACGT" * int(rng.integers(1, 60)); r = (b"ACGT" * 80)[int(rng.integers(0, 4)):][:int(rng.integers(1, 300))]; d = int(rng.integers(-20, 20))
+        elif kind == 4:
+            q = b"A" * int(rng.integers(1, 50)); r = b"C" * int(rng.integers(1, 50)); d = int(rng.integers(-60, 60))        # no match at all
+        elif kind == 5:
+            q = random_seqs(rng, 1, 100, 250)[0]; r = random_seqs(rng, 1, 5, 40)[0] + mutate(rng, q, 0.05, 0.02); d = len(r) - len(q) + int(rng.integers(-2, 3))
+        elif kind == 6:
+            q = random_seqs(rng, 1, 20, 60)[0]; r = random_seqs(rng, 1, 20, 60)[0]; d = int(rng.integers(-200, 200))       # bands that miss the matrix
+        else:
+            q = random_seqs(rng, 1, 180, 250)[0]; r = mutate(rng, q, 0.2, 0.1); d = 0
+        qs.append(q); rs.append(r); dg.append(d)
+    dg = np.array(dg, dtype=np.int32)
+    al = pkg.Aligner.new().local().matrix(pm).gap_open(5).gap_extend(2).build()
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    want = orc.align_banded_batch(orc.SW, qb, qo, rb, ro, 5, 2, om, k, dg)
+    got = al.align_batch_banded(qs, rs, k, dg)
+    assert pkg.lib.pmx_last_kernel().decode() == "pmx_banded_packed_kernel"
+    bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
+    assert len(bad) == 0, (k, bad[:6], got[bad[:4]], want[bad[:4]], [(len(qs[x]), len(rs[x]), int(dg[x])) for x in bad[:4]])
+    monkeypatch.setenv("PMX_BANDED_NO_PACKED", "1")
+    ref = al.align_batch_banded(qs, rs, k, dg)
+    assert pkg.lib.pmx_last_kernel().decode() == "pmx_banded_staged_kernel"
+    assert (ref == got).all()

@@ -116,6 +116,8 @@ def _suite(pkg, orc):
         cases.append(("%s/dna/width8" % mode, w8))
     alb = builder(dna_p, 5, 2, "nw").build()
     cases.append(("nw/dna/banded", lambda: (rec(alb.align_batch_banded(dq[:400], dr[:400], 12)),)))
+    albs = builder(dna_p, 5, 2, "sw").build()                       # banded local: the packed int16 form
+    cases.append(("sw/dna/banded", lambda: (rec(albs.align_batch_banded(dq[:401], dr[:401], 12)),)))
     alt = builder(dna_p, 5, 2, "sg").use_table().build()
 
     def table():
