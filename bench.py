@@ -535,7 +535,7 @@ class Cfg5(Workload):
                               "kernel": self.pkg.lib.pmx_last_kernel().decode(),
                               "never_above_full_pass": same, "share_of_pairs_with_the_full_score": round(kept, 4),
                               "note": "extension, no reference counterpart: |(j - i) - diag| <= band with diag = end_ref - end_query of "
-                                      "the first pass; only the band's cells are computed (32-bit lanes)"}}
+                                      "the first pass; only the band's cells are computed (packed int16 lanes, two pairs per lane group)"}}
 
     def cpu_baseline(self, last_out):
         from oracle import oracle as orc

@@ -616,7 +616,7 @@ int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMat
         const int QCp = ((max_qlen + 2 * 160 + 3) & ~3), RCp = ((max_rlen + 2 * 160 + 3) & ~3);
         const size_t ldsp = (size_t)NPWp * ((size_t)QCp * 2 + RCp);
         if (ldsp <= 150 * 1024) {
-#define LPK(LP) do { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_banded_packed_kernel<LP>)); if (rc) return rc; \
+#define LPK(LP) do { if (ldsp > 48 * 1024) { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_banded_packed_kernel<LP>), 156 * 1024); if (rc) return rc; } \
         hipLaunchKernelGGL((pmx_banded_packed_kernel<LP>), dim3((unsigned)((n + NPWp - 1) / NPWp)), dim3(64), ldsp, stream, \
                            qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, open, ext, band, diag, QCp, RCp, out); } while (0)
             if (band <= 15) LPK(16); else if (band <= 31) LPK(32); else LPK(64);
