@@ -15,6 +15,7 @@
 // 32-bit lanes (no saturation inside a band), score + end positions with the oracle's rules for every mode.
 #include "pmx_common.h"
 #include "pmx_switches.h"
+#include <algorithm>
 
 #define B_NEG (INT32_MIN / 2)
 
@@ -424,7 +425,8 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
                               const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff, long long n,
                               const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap, int msize,
                               int open, int ext, int band, const int32_t *__restrict__ diag,
-                              int QC, int RC /* staging capacity per pair, margins included */, pmx_record_t *__restrict__ out)
+                              int QC, int RC /* staging capacity per pair, margins included */,
+                              const unsigned *__restrict__ perm /* optional processing order: position -> pair */, pmx_record_t *__restrict__ out)
 {
     constexpr int MG = 160;                                  // pad symbols in front of and behind every staged sequence
     __shared__ unsigned char matp[(PMX_MAX_FAST_MSIZE + 1) * (PMX_MAX_FAST_MSIZE + 1)];    // score + open as a byte; row / column msize = the pad symbol
@@ -441,17 +443,18 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
     constexpr int NG = 64 / LP, NPW = 2 * NG;                // lane groups, pairs per wave
     const int lane = threadIdx.x, x = lane % LP, grp = lane / LP;
     // per half: geometry of the pair
-    long long pairH[2]; bool haveH[2]; int qlH[2], rlH[2], d0H[2], I0H[2], J0H[2], nstH[2]; bool hitH[2];
+    long long pairH[2]; bool haveH[2]; int qlH[2], rlH[2], d0H[2], I0H[2], J0H[2], nstH[2], cwH[2], wlenH[2]; bool hitH[2];
     int nsteps = 0;
     unsigned short *qm_all = reinterpret_cast<unsigned short *>(dyn);            // [NPW][QC]: symbol * MS1, 16 bits
     unsigned char *rm_all = dyn + (size_t)NPW * QC * 2;                           // [NPW][RC]
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const long long pair = (long long)blockIdx.x * NPW + 2 * grp + h;
-        pairH[h] = pair; haveH[h] = pair < n;
-        const long long pp = haveH[h] ? pair : n - 1;
+        const long long pos = (long long)blockIdx.x * NPW + 2 * grp + h;
+        haveH[h] = pos < n;
+        const long long pp = perm ? (long long)perm[haveH[h] ? pos : n - 1] : (haveH[h] ? pos : n - 1);
+        pairH[h] = pp;
         const long long qb = q_shared ? 0 : qoff[pp], rb = roff[pp];
-        const int ql = min(q_shared ? q_shared : (int)(qoff[pp + 1] - qb), QC - 2 * MG), rl = min((int)(roff[pp + 1] - rb), RC - 2 * MG);
+        const int ql = min(q_shared ? q_shared : (int)(qoff[pp + 1] - qb), QC - 2 * MG), rl = (int)(roff[pp + 1] - rb);   // (the reference is staged by window)
         qlH[h] = ql; rlH[h] = rl;
         const int d0 = diag ? diag[pp] : 0;
         d0H[h] = d0;
@@ -472,22 +475,32 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
         nstH[h] = ns;
         nsteps = max(nsteps, ns);
         I0H[h] = ((s0 + band - d0) >> 1) - x; J0H[h] = I0H[h] + 2 * x - band + d0;
+        // Only the WINDOW of the reference the band crosses is staged: columns cw .. cw + band + steps / 2 (lane x starts at column
+        // cw + x and moves one column per two steps) -- about qlen + 2 band symbols of a reference that may be five times as long; the
+        // LDS this saves is occupancy.  Position t of the staged window = column cw - 8 + t.
+        const int cw = ((s0 + band - d0) >> 1) - band + d0;
+        cwH[h] = cw;
+        const int wlen = min(band + (ns >> 1) + 24, RC - 16);
         // stage this pair's sequences (all lanes of the wave work on one pair at a time: its offsets come from its group's lane 0)
 #pragma unroll
         for (int g2 = 0; g2 < NG; ++g2) {
             const long long qb2 = __shfl(qb, g2 * LP, 64), rb2 = __shfl(rb, g2 * LP, 64);
             const int ql2 = __shfl(ql, g2 * LP, 64), rl2 = __shfl(rl, g2 * LP, 64);
+            const int cw2 = __shfl(cw, g2 * LP, 64), wl2 = __shfl(wlen, g2 * LP, 64);
             unsigned short *qd = qm_all + (size_t)(2 * g2 + h) * QC;
             unsigned char *rd = rm_all + (size_t)(2 * g2 + h) * RC;
-            for (int t = lane; t < ql2 + 2 * MG; t += 64) {
-                const int i = t - MG;
-                qd[t] = (unsigned short)(((i >= 0 && i < ql2) ? (int)map[qbuf[qb2 + i]] : msize) * MS1);
+            if (!(q_shared && (g2 || h))) {                  // one shared query: staged once, every pair reads that copy
+                for (int t = lane; t < ql2 + 2 * MG; t += 64) {
+                    const int i = t - MG;
+                    qd[t] = (unsigned short)(((i >= 0 && i < ql2) ? (int)map[qbuf[qb2 + i]] : msize) * MS1);
+                }
             }
-            for (int t = lane; t < rl2 + 2 * MG; t += 64) {
-                const int j = t - MG;
-                rd[t] = (unsigned char)((j >= 0 && j < rl2) ? (int)map[rbuf[rb2 + j]] : msize);
+            for (int t = lane; t < wl2 + 16; t += 64) {
+                const int j = cw2 - 8 + t;
+                rd[t] = (unsigned char)((j >= 0 && j < rl2 && t < wl2 + 8) ? (int)map[rbuf[rb2 + j]] : msize);
             }
         }
+        wlenH[h] = wlen;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, off, 64));
@@ -496,62 +509,69 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
 
     const int B = 1024 + open + ext;                          // true 0
     const int B2 = B * 0x00010001, vOpen = open * 0x00010001, vExt = ext * 0x00010001;
+    int bH = B2, bT = 0;                                      // best (only a score above 0 is tracked) and the step where it was first exceeded
     const int keep_odd = x >= band ? 0 : -1;                  // the lane's odd diagonal lies outside the band: forced to "minus infinity"
     const int floorv = x <= band ? B2 : 0;                    // zero floor only inside the band
     const int first_ok = x == 0 ? 0 : -1, last_ok = x == LP - 1 ? 0 : -1;
     auto below = [&](int v) -> int {                          // value of lane x - 1, 0 ("minus infinity") at the band's first lane
-        int r = __builtin_amdgcn_update_dpp(0, v, LP == 16 ? 0x111 /*row_shr:1*/ : 0x138 /*wave_shr:1*/, 0xF, 0xF, true);
+        int r = __builtin_amdgcn_mov_dpp(v, LP == 16 ? 0x111 /*row_shr:1*/ : 0x138 /*wave_shr:1*/, 0xF, 0xF, true);      // (bound_ctrl: no `old` register)
         if (LP == 32) r &= first_ok;
         return r;
     };
     auto above = [&](int v) -> int {                          // value of lane x + 1, 0 at the group's last lane
-        int r = __builtin_amdgcn_update_dpp(0, v, LP == 16 ? 0x101 /*row_shl:1*/ : 0x130 /*wave_shl:1*/, 0xF, 0xF, true);
+        int r = __builtin_amdgcn_mov_dpp(v, LP == 16 ? 0x101 /*row_shl:1*/ : 0x130 /*wave_shl:1*/, 0xF, 0xF, true);
         if (LP == 32) r &= last_ok;
         return r;
     };
     const b_v2s sh15 = {15, 15};
+    // best and its step, per half: 0xFFFF where H > best (one packed subtract + one shift), the step inserted under that mask
+    auto track = [&](int H, int tau) {
+        const int m = BI32((BPK(bH) - BPK(H)) >> sh15);
+        bH = bp_max3(bH, H, H);
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bT) : "v"(m), "s"(tau * 0x00010001), "v"(bT));
+    };
     // LDS read positions (element indices), clamped into the trailing pad once a pair has run past its sequences
     int qpos[2], rpos[2], qend[2], rend[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        qpos[h] = I0H[h] + MG; rpos[h] = J0H[h] + MG;
-        qend[h] = qlH[h] + MG + 8; rend[h] = rlH[h] + MG + 8;                     // 8 .. MG pads follow
+        qpos[h] = I0H[h] + MG; rpos[h] = J0H[h] - cwH[h] + 8;                     // (reference: position in the staged window)
+        qend[h] = qlH[h] + MG + 8; rend[h] = wlenH[h] + 8;                        // 8 or more pads follow
         qpos[h] = min(max(qpos[h], 0), qend[h]); rpos[h] = min(max(rpos[h], 0), rend[h]);
         // lanes beyond the band read pad symbols only: on real symbols their unfloored, unmasked cells could climb along a run of
         // matches (low-complexity sequences) from "minus infinity" into the range of real values -- B is 1 024, not 2^30
         if (x > band) { qpos[h] = qend[h]; rpos[h] = rend[h]; }
     }
-    const unsigned short *qmA = qm_all + (size_t)(2 * grp) * QC, *qmB = qmA + QC;
+    const unsigned short *qmA = q_shared ? qm_all : qm_all + (size_t)(2 * grp) * QC, *qmB = q_shared ? qm_all : qmA + QC;
     const unsigned char *rmA = rm_all + (size_t)(2 * grp) * RC, *rmB = rmA + RC;
 
     // state: everything "minus infinity" (0) except nothing -- the pad cells in front of the matrix produce the zero boundary
     int Ho1 = 0, Ho2 = 0, Ee1 = 0, Fe1 = 0;                   // H - open of the lane's previous cell and of the one before; E - ext; F - ext
-    int bH = B2, bT = 0;                                      // best (only a score above 0 is tracked) and the step where it was first exceeded
-    for (int t0 = 0; t0 < nsteps; t0 += 8) {
-        int sc[8];
-        {
-            int mq[2][4], mr[2][5];
+    // (fetching a block's scores one block ahead was measured and lost: 53.3 -> 58.9 ms on cfg 5's second pass -- the other waves
+    //  of the SIMD already cover the two dependent LDS reads, the extra register moves cost more)
+    auto fetch = [&](int (&dst)[8]) {
+        int mq[2][4], mr[2][5];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { mq[0][k] = qmA[qpos[0] + k]; mq[1][k] = qmB[qpos[1] + k]; }
+        for (int k = 0; k < 4; ++k) { mq[0][k] = qmA[qpos[0] + k]; mq[1][k] = qmB[qpos[1] + k]; }
 #pragma unroll
-            for (int k = 0; k < 5; ++k) { mr[0][k] = rmA[rpos[0] + k]; mr[1][k] = rmB[rpos[1] + k]; }
+        for (int k = 0; k < 5; ++k) { mr[0][k] = rmA[rpos[0] + k]; mr[1][k] = rmB[rpos[1] + k]; }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                sc[2 * k] = (int)matp[mq[0][k] + mr[0][k]] | ((int)matp[mq[1][k] + mr[1][k]] << 16);
-                sc[2 * k + 1] = (int)matp[mq[0][k] + mr[0][k + 1]] | ((int)matp[mq[1][k] + mr[1][k + 1]] << 16);
-            }
+        for (int k = 0; k < 4; ++k) {
+            dst[2 * k] = (int)matp[mq[0][k] + mr[0][k]] | ((int)matp[mq[1][k] + mr[1][k]] << 16);
+            dst[2 * k + 1] = (int)matp[mq[0][k] + mr[0][k + 1]] | ((int)matp[mq[1][k] + mr[1][k + 1]] << 16);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) { qpos[h] = min(qpos[h] + 4, qend[h]); rpos[h] = min(rpos[h] + 4, rend[h]); }
+    };
+    int sc[8];
+    for (int t0 = 0; t0 < nsteps; t0 += 8) {
+        fetch(sc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             {   // even step: left from lane x - 1, up = own previous cell
                 const int lHo = below(Ho1), lEe = below(Ee1);
                 const int E = bp_max3(lEe, lHo, floorv), F = bp_max3(Fe1, Ho1, Ho1);
                 const int H = bp_max3(Ho2 + sc[2 * k], E, F);
-                const int m = BI32((BPK(bH) - BPK(H)) >> sh15);          // 0xFFFF where H > best
-                bH = bp_max3(bH, H, H);
-                bT = (bT & ~m) | (((t0 + 2 * k) * 0x00010001) & m);
+                track(H, t0 + 2 * k);
                 Ho2 = Ho1; Ho1 = bp_subus(H, vOpen); Ee1 = bp_subus(E, vExt); Fe1 = bp_subus(F, vExt);
             }
             {   // odd step: up from lane x + 1, left = own previous cell
@@ -559,9 +579,7 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
                 int E = bp_max3(Ee1, Ho1, floorv), F = bp_max3(uFe, uHo, uHo);
                 int H = bp_max3(Ho2 + sc[2 * k + 1], E, F);
                 H &= keep_odd; E &= keep_odd; F &= keep_odd;
-                const int m = BI32((BPK(bH) - BPK(H)) >> sh15);
-                bH = bp_max3(bH, H, H);
-                bT = (bT & ~m) | (((t0 + 2 * k + 1) * 0x00010001) & m);
+                track(H, t0 + 2 * k + 1);
                 Ho2 = Ho1; Ho1 = bp_subus(H, vOpen); Ee1 = bp_subus(E, vExt); Fe1 = bp_subus(F, vExt);
             }
         }
@@ -596,7 +614,7 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
 int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,
                       const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
                       int max_qlen, int max_rlen, int band, const int32_t *diag, pmx_record_t *out, hipStream_t stream,
-                      const char **kernel_name)
+                      const char **kernel_name, void *sort_scratch)
 {
     if (n <= 0) return 0;
     if (pmx_env("PMX_NO_FAST_BANDED")) return 1;
@@ -613,12 +631,19 @@ int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMat
         m.min + open >= 0 && m.max + open <= 255 && m.msize <= PMX_MAX_FAST_MSIZE - 1 &&
         (long long)(max_qlen < max_rlen ? max_qlen : max_rlen) * (m.max > 0 ? m.max : 0) + 1024 + open + ext + (m.max > 0 ? m.max : 0) < 31000) {
         const int LPp = band <= 15 ? 16 : band <= 31 ? 32 : 64, NPWp = 2 * (64 / LPp);
-        const int QCp = ((max_qlen + 2 * 160 + 3) & ~3), RCp = ((max_rlen + 2 * 160 + 3) & ~3);
+        // (reference: only the window the band crosses is staged -- at most band + steps / 2 + 24 symbols, steps <= 2 (qlen + band) + 4)
+        const int QCp = ((max_qlen + 2 * 160 + 3) & ~3), RCp = ((std::min(max_rlen, max_qlen + 2 * band + 8) + band + 48 + 3) & ~3);
         const size_t ldsp = (size_t)NPWp * ((size_t)QCp * 2 + RCp);
         if (ldsp <= 150 * 1024) {
+            // neighbours in one lane group run for the longer of their two bands: process the pairs in the order of their bands' lengths
+            const unsigned *perm = nullptr;
+            if (sort_scratch && n >= 4096) {
+                const int rc = pmx_build_band_perm(qoff, q_shared, roff, diag, band, n, sort_scratch, &perm, stream);
+                if (rc < 0) return rc;
+            }
 #define LPK(LP) do { if (ldsp > 48 * 1024) { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_banded_packed_kernel<LP>), 156 * 1024); if (rc) return rc; } \
         hipLaunchKernelGGL((pmx_banded_packed_kernel<LP>), dim3((unsigned)((n + NPWp - 1) / NPWp)), dim3(64), ldsp, stream, \
-                           qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, open, ext, band, diag, QCp, RCp, out); } while (0)
+                           qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, open, ext, band, diag, QCp, RCp, perm, out); } while (0)
             if (band <= 15) LPK(16); else if (band <= 31) LPK(32); else LPK(64);
 #undef LPK
             if (kernel_name) *kernel_name = "pmx_banded_packed_kernel";

@@ -84,6 +84,9 @@ int pmx_launch_unpack2(const uint8_t *in, uint8_t *out, long long lo, long long 
 // Length-sorted processing order for ragged batches (pmx_sort.hip).
 size_t pmx_sort_scratch_bytes(long long n);
 int pmx_build_length_perm(const int64_t *d_roff, long long n, void *scratch, const unsigned **perm_out, hipStream_t stream);
+// Processing order for banded batches: by the number of anti-diagonal steps of each pair's band (same scratch size).
+int pmx_build_band_perm(const int64_t *d_qoff, int q_shared, const int64_t *d_roff, const int32_t *d_diag, int band, long long n,
+                        void *scratch, const unsigned **perm_out, hipStream_t stream);
 
 // Fast path: global / semi-global, score + end positions, biased packed lanes (pmx_nwsg16.hip).
 int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
@@ -160,7 +163,8 @@ static inline bool pmx_general_lds_fits(int mat_rows, int msize, int max_rlen)
 // computed.  0 launched, 1 not eligible (the general kernel masks instead), <0 HIP error.
 int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,
                       const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
-                      int max_qlen, int max_rlen, int band, const int32_t *diag, pmx_record_t *out, hipStream_t stream, const char **kernel_name = nullptr);
+                      int max_qlen, int max_rlen, int band, const int32_t *diag, pmx_record_t *out, hipStream_t stream, const char **kernel_name = nullptr,
+                      void *sort_scratch = nullptr /* pmx_sort_scratch_bytes(n) bytes: lets the packed local form pair up bands of equal length */);
 
 // Score tables / last rows and columns, row by row at HBM write speed (pmx_table.hip).  0 launched, 1 not eligible, <0 HIP error.
 int pmx_launch_table(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,

@@ -39,6 +39,41 @@ int pmx_build_length_perm(const int64_t *d_roff, long long n, void *scratch, con
     return 0;
 }
 
+// ---- banded batches: processing order by the number of anti-diagonal steps of a pair's band -------------------------------------------
+// The packed banded kernel (pmx_banded.hip) runs two pairs per lane group for max(steps A, steps B): neighbours in the processing
+// order should need about the same number of steps.  key = steps of the band inside the matrix (the kernel's own formula).
+__global__ void pmx_band_keys_kernel(const int64_t *qoff, int q_shared, const int64_t *roff, const int32_t *diag, int band, long long n,
+                                     unsigned *keys, unsigned *vals)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int ql = q_shared ? q_shared : (int)(qoff[k + 1] - qoff[k]), rl = (int)(roff[k + 1] - roff[k]);
+    const int d0 = diag ? diag[k] : 0, dlo = d0 - band, dhi = d0 + band;
+    int s_first = 0;
+    if (dlo > 0) s_first = dlo; else if (dhi < 0) s_first = -dhi;
+    int i1 = ql - 1, j1 = rl - 1, s_last = -1;
+    if (j1 - i1 > dhi) j1 = i1 + dhi; else if (j1 - i1 < dlo) i1 = j1 - dlo;
+    if (i1 >= 0 && j1 >= 0) s_last = i1 + j1;
+    if (dlo > rl - 1 || dhi < -(ql - 1)) s_last = -1;
+    int ns = s_last - s_first + 1; if (ns < 0) ns = 0;
+    keys[k] = (unsigned)ns; vals[k] = (unsigned)k;
+}
+int pmx_build_band_perm(const int64_t *d_qoff, int q_shared, const int64_t *d_roff, const int32_t *d_diag, int band, long long n,
+                        void *scratch, const unsigned **perm_out, hipStream_t stream)
+{
+    if (n <= 0 || n >= (1LL << 32)) return 1;
+    unsigned *keys_in = (unsigned *)scratch, *keys_out = keys_in + n, *vals_in = keys_out + n, *perm = vals_in + n;
+    void *temp = (void *)(((uintptr_t)(perm + n) + 255) & ~(uintptr_t)255);
+    size_t temp_bytes = 0;
+    (void)rocprim::radix_sort_pairs_desc(nullptr, temp_bytes, keys_in, keys_out, vals_in, perm, (size_t)n, 0, 32, stream);
+    hipLaunchKernelGGL(pmx_band_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_qoff, q_shared, d_roff, d_diag, band, n,
+                       keys_in, vals_in);
+    hipError_t e = rocprim::radix_sort_pairs_desc(temp, temp_bytes, keys_in, keys_out, vals_in, perm, (size_t)n, 0, 32, stream);
+    if (e != hipSuccess) return -(int)e;
+    *perm_out = perm;
+    return 0;
+}
+
 // ---- device CIGAR entry: exclusive scan of per-pair text lengths (int32) into int64 offsets ----
 struct PmxWidenI32 { __device__ __host__ int64_t operator()(int32_t v) const { return (int64_t)v; } };
 
