@@ -135,6 +135,12 @@ def _suite(pkg, orc):
             res = alst.align(dq[5] * 3, dr[5] * 3)
             return tuple(np.array(getattr(res, "get_%s_table" % k)().as_slice(), copy=True) for k in ("score", "matches", "similar", "length"))
         cases.append(("%s/dna/statstable1" % mode, stats_table))
+    # many long pairs: the band kernel's throughput shape (1 024-row bands)
+    lq5 = random_seqs(rng, 520, 2100, 2200); lr5 = random_seqs(rng, 520, 60, 200)
+    al5 = builder(dna_p, 5, 2, "sg").build()
+    cases.append(("sg/dna/long520", lambda: (rec(al5.align_batch(lq5, lr5)),)))
+    (q5b, q5o), (r5b, r5o) = orc.pack(lq5), orc.pack(lr5)
+    expect["sg/dna/long520"] = orc.align_batch(orc.SG, q5b, q5o, r5b, r5o, 5, 2, dna_o)
     for mode in ("sw", "nw", "sg"):                    # one-pair trace table (table kernel with trace bytes, or the general kernel)
         alr = builder(b62_p, 11, 1, mode).use_trace().build()
 
