@@ -1342,10 +1342,9 @@ static int long_batch(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch 
                                       pen_row ? -((long long)cfg->open + (long long)(max_rlen - 1) * cfg->extend) : 0LL);
         if (n == 1 && lo < -(long long)wmax - 1) force_sat = 1; else return 1;     // (inside the range: the general kernel tracks min / max H)
     }
-    // R = 4 (256-row bands): the most bands, the shortest step -- one call's latency.  Enough long pairs to fill the chip with
-    // 1 024-row bands (R = 16): what a step does once is shared by four times the rows -- throughput.
+    // R = 4 (256-row bands) also for batches that fill the chip: 1 024-row bands (R = 16) share a step's fixed work among four
+    // times the rows, but the longer dependent chain per step costs more (512 x 5 kbp^2: 5.0 ms against 6.5 ms, measured)
     int R = 4; long long bstride = 0; int nbmax = 0;
-    if (max_qlen >= 768 && n * (((long long)max_qlen + 1023) / 1024) >= 1536 && !pmx_env("PMX_LONG_ROWS4")) R = 16;
     size_t per_pair = pmx_long_scratch_bytes(1, max_qlen, max_rlen, R, &bstride, &nbmax);
     if (per_pair > ((size_t)4 << 30)) { R = 16; per_pair = pmx_long_scratch_bytes(1, max_qlen, max_rlen, R, &bstride, &nbmax); }
     size_t fb = 0, tb = 0;

@@ -51,7 +51,6 @@ struct PmxSwitchDoc { const char *name, *kind, *what; };
     X("PMX_GENERAL_ONE_WAVE",         "force", "general kernel: one wave per pair also for few long pairs (no pipelined sharing of a pair among the waves of a workgroup)") \
     X("PMX_GENERAL_CHUNK_BYTES",      "value", "batches through the general kernel (score fallback, score tables): bytes of boundary scratch per chunk (tests force one-pair chunks)") \
     X("PMX_NO_LONG_KERNEL",           "force", "few long pairs: the per-pair kernels instead of the kernel that spreads one pair's query bands over the chip") \
-    X("PMX_LONG_ROWS4",               "force", "long-pair kernel over a batch: 256-row bands (4 rows per lane) also where 1 024-row bands would be chosen") \
     X("PMX_LONG_CHUNK_BYTES",         "value", "long-pair kernel over a batch: bytes of boundary scratch per chunk (tests force several chunks)") \
     X("PMX_NO_FAST_TABLE",            "force", "score tables: general kernel instead of the table kernel") \
     X("PMX_CIGAR_SWAP_ID",            "convention", "CIGAR letters / BAM ops of the two gap states exchanged (I <-> D) in get_cigar, ssw and batch CIGAR text") \

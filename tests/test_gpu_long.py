@@ -186,19 +186,3 @@ def test_batches_outside_every_packed_window_take_the_band_kernel(pkg, orc, mode
         got = _rec(_builder(pkg, pm, 5, 2, mode).build().align_batch(lq, lr))
         assert LONG in pkg.lib.pmx_last_kernel().decode()
         assert (got == want).all(), chunk
-
-
-def test_many_long_pairs_take_the_1024_row_bands(pkg, orc):
-    """enough long pairs to fill the chip: 1 024-row bands (16 rows per lane), all modes, ragged lengths, against the oracle"""
-    rng = np.random.default_rng(9996)
-    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
-    qs = random_seqs(rng, 800, 1, 2300)
-    qs[0] = random_seqs(rng, 1, 2300, 2300)[0]
-    rs = [mutate(rng, q, 0.1, 0.04)[:400] if k % 2 else random_seqs(rng, 1, 1, 400)[0] for k, q in enumerate(qs)]
-    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
-    for mode in (0, 1, 2):
-        got = _rec(_builder(pkg, pm, 5, 2, mode).build().align_batch(qs, rs))
-        assert "pmx_long32_kernel<16>" in pkg.lib.pmx_last_kernel().decode(), pkg.lib.pmx_last_kernel()
-        want = orc.align_batch(mode, qb, qo, rb, ro, 5, 2, om)
-        bad = np.nonzero((got != want).any(axis=1))[0]
-        assert len(bad) == 0, (mode, bad[:5], got[bad[:3]], want[bad[:3]], [(len(qs[k]), len(rs[k])) for k in bad[:3]])

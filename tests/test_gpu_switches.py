@@ -135,7 +135,7 @@ def _suite(pkg, orc):
             res = alst.align(dq[5] * 3, dr[5] * 3)
             return tuple(np.array(getattr(res, "get_%s_table" % k)().as_slice(), copy=True) for k in ("score", "matches", "similar", "length"))
         cases.append(("%s/dna/statstable1" % mode, stats_table))
-    # many long pairs: the band kernel's throughput shape (1 024-row bands)
+    # many long pairs (queries beyond 2 048 rows): the band kernel over a batch
     lq5 = random_seqs(rng, 520, 2100, 2200); lr5 = random_seqs(rng, 520, 60, 200)
     al5 = builder(dna_p, 5, 2, "sg").build()
     cases.append(("sg/dna/long520", lambda: (rec(al5.align_batch(lq5, lr5)),)))
