@@ -548,12 +548,17 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
     int Ho1 = 0, Ho2 = 0, Ee1 = 0, Fe1 = 0;                   // H - open of the lane's previous cell and of the one before; E - ext; F - ext
     // (fetching a block's scores one block ahead was measured and lost: 53.3 -> 58.9 ms on cfg 5's second pass -- the other waves
     //  of the SIMD already cover the two dependent LDS reads, the extra register moves cost more)
+    // (the kernel is LDS-bound: a block's fifth reference symbol is the next block's first and is carried over, not read again;
+    //  once a position is clamped into the trailing pads the carried symbol is a pad as well)
+    int rcarry[2] = {(int)rmA[rpos[0]], (int)rmB[rpos[1]]};
     auto fetch = [&](int (&dst)[8]) {
         int mq[2][4], mr[2][5];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { mq[0][k] = qmA[qpos[0] + k]; mq[1][k] = qmB[qpos[1] + k]; }
+        mr[0][0] = rcarry[0]; mr[1][0] = rcarry[1];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { mr[0][k] = rmA[rpos[0] + k]; mr[1][k] = rmB[rpos[1] + k]; }
+        for (int k = 1; k < 5; ++k) { mr[0][k] = rmA[rpos[0] + k]; mr[1][k] = rmB[rpos[1] + k]; }
+        rcarry[0] = mr[0][4]; rcarry[1] = mr[1][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             dst[2 * k] = (int)matp[mq[0][k] + mr[0][k]] | ((int)matp[mq[1][k] + mr[1][k]] << 16);

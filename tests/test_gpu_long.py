@@ -186,3 +186,52 @@ def test_batches_outside_every_packed_window_take_the_band_kernel(pkg, orc, mode
         got = _rec(_builder(pkg, pm, 5, 2, mode).build().align_batch(lq, lr))
         assert LONG in pkg.lib.pmx_last_kernel().decode()
         assert (got == want).all(), chunk
+
+
+def _seeds(default):
+    spec = os.environ.get("PMX_FUZZ_SEEDS")
+    return [int(x) for x in spec.split(",")] if spec else default
+
+
+@pytest.mark.parametrize("seed", _seeds([301, 302, 303]))
+def test_fuzz_band_kernel_shapes_modes_and_scoring(pkg, orc, seed):
+    """random modes, free-end sets, gap models (open < extend and extend = 0 included), matrices over 2-9 letters, lengths around the
+    256-row bands and the 64-column chunks, 1-16 pairs per call: pmx_long32_kernel against the oracle"""
+    rng = np.random.default_rng(seed)
+    for it in range(14):
+        na = int(rng.integers(2, 10))
+        letters = bytes(b"ACGTRYKMS"[:na])
+        match, mismatch = int(rng.integers(1, 9)), -int(rng.integers(0, 9))
+        pm, om = pkg.Matrix.create(letters, match, mismatch), orc.Matrix.create(letters.decode(), match, mismatch)
+        al = np.frombuffer(letters, dtype=np.uint8)
+        open_, ext = int(rng.integers(0, 12)), int(rng.integers(0, 7))
+        n = int(rng.integers(1, 17))
+        big_q = int(rng.choice([512, 513, 767, 768, 1024, 1025, 1500, 2049, 2600]))
+        big_r = max(int(3.2e6 / big_q) + int(rng.integers(1, 400)), 64)
+        qs = [random_seqs(rng, 1, big_q, big_q, al)[0]] + random_seqs(rng, n - 1, 1, big_q, al)
+        rs = []
+        for k, q in enumerate(qs):
+            L = big_r if k == 0 else int(rng.choice([1, 63, 64, 65, 127, 128, 129, 200, 1000, big_r]))
+            base = mutate(rng, q, 0.1, 0.05, al) if rng.random() < 0.6 else random_seqs(rng, 1, L, L, al)[0]
+            rs.append((base + random_seqs(rng, 1, L, L, al)[0])[:L])
+        mode = int(rng.integers(0, 3))
+        sg = int(rng.integers(1, 16)) if mode == 1 else 15
+        b = _builder(pkg, pm, open_, ext, mode)
+        if mode == 1:
+            b.allow_query_gaps([n_ for f, n_ in ((1, "prefix"), (2, "suffix")) if sg & f]).allow_ref_gaps([n_ for f, n_ in ((4, "prefix"), (8, "suffix")) if sg & f])
+            if sg in (3, 12, 15) or (sg & 3) == 0 or (sg & 12) == 0:
+                pass
+        got = _rec(b.build().align_batch(qs, rs))
+        # (a free-end set the builder cannot name -- no gaps allowed on one sequence -- resolves to that sequence's default)
+        eff = sg if mode == 1 else 15
+        if mode == 1:
+            qpart, dpart = sg & 3, sg & 12
+            eff = (qpart | dpart) if (qpart or dpart) else 15
+            if qpart == 3 and dpart == 12:
+                eff = 15
+        assert LONG in pkg.lib.pmx_last_kernel().decode(), (pkg.lib.pmx_last_kernel(), mode, open_, ext)
+        qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+        want = orc.align_batch(mode, qb, qo, rb, ro, open_, ext, om, sg_flags=eff)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, (seed, it, mode, eff, open_, ext, match, mismatch, na, bad[:4], got[bad[:4]], want[bad[:4]],
+                               [(len(qs[k]), len(rs[k])) for k in bad[:4]])

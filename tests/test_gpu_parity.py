@@ -1498,3 +1498,42 @@ def test_nwsg16_permtable_form_with_traceback_and_statistics(pkg, orc):
             ws = orc.align_stats_sample(mode, idx, qb, qo, rb, ro, 5, 2, om)
             got = np.stack([r2["score"][idx], r2["end_query"][idx], r2["end_ref"][idx], st["matches"][idx], st["similar"][idx], st["length"][idx]], axis=1)
             assert (got == ws[:, :6]).all(), (L, mode)
+
+
+@pytest.mark.parametrize("seed", _seeds([401, 402]))
+def test_fuzz_permtable_form_blocks_and_fallback(pkg, orc, seed):
+    """random equal-length DNA batches with blocks the perm-table form has to leave (ragged lengths, wildcards, lower case), random
+    scoring inside and outside its window, every mode / free-end set / width incl. 8: both forms inside one call against the oracle"""
+    rng = np.random.default_rng(seed)
+    for it in range(10):
+        L = int(rng.choice([20, 49, 50, 64, 75, 100, 127, 128, 150, 152, 160, 200, 250, 256]))
+        n = int(rng.integers(2100, 4400))
+        match, mismatch = [(2, -3), (1, -1), (3, -2), (5, -4), (1, -3)][int(rng.integers(0, 5))]
+        open_, ext = [(5, 2), (3, 1), (11, 1), (4, 4), (6, 0)][int(rng.integers(0, 5))]
+        pm, om = pkg.Matrix.create(b"ACGT", match, mismatch), orc.Matrix.create("ACGT", match, mismatch)
+        qs = random_seqs(rng, n, L, L)
+        rs = [mutate(rng, q, 0.1, 0.04) if k % 2 else random_seqs(rng, 1, max(1, L - 30), L + 30)[0] for k, q in enumerate(qs)]
+        for k in rng.integers(0, n, size=12):
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                p = int(rng.integers(0, L)); qs[k] = qs[k][:p] + b"N" + qs[k][p + 1:]
+            elif kind == 1:
+                qs[k] = qs[k][:int(rng.integers(1, L + 1))]
+            else:
+                qs[k] = qs[k].lower(); rs[k] = rs[k].lower()
+        mode = int(rng.integers(0, 2))
+        sg = int(rng.integers(1, 16)) if mode == 1 else 15
+        width = [16, None, 32, 8][int(rng.integers(0, 4))]
+        b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext)
+        if width:
+            b.solution_width(width)
+        [b.global_, b.semi_global][mode]()
+        if mode == 1:
+            b.allow_query_gaps([n_ for f, n_ in ((1, "prefix"), (2, "suffix")) if sg & f]).allow_ref_gaps([n_ for f, n_ in ((4, "prefix"), (8, "suffix")) if sg & f])
+        got = b.build().align_batch(qs, rs)
+        qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+        want = orc.align_stats_sample(mode, np.arange(n), qb, qo, rb, ro, open_, ext, om, sg_flags=sg, bits=width or 0)
+        ok = want[:, 6] == 0
+        assert ((got["flags"] & 1) == want[:, 6]).all(), (seed, it, mode, sg, width, L)
+        bad = np.nonzero(ok & ((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2])))[0]
+        assert len(bad) == 0, (seed, it, mode, sg, width, L, open_, ext, match, mismatch, pkg.lib.pmx_last_kernel(), bad[:5], got[bad[:3]], want[bad[:3]])
