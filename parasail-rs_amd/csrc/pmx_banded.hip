@@ -419,8 +419,16 @@ __device__ __forceinline__ int bp_subus(int a, int b)         // v_pk_sub_u16 cl
     return __builtin_bit_cast(int, __builtin_elementwise_sub_sat(__builtin_bit_cast(b_v2us, a), __builtin_bit_cast(b_v2us, b)));
 }
 
-template <int LP>
-__global__ __launch_bounds__(64)
+// FORM 0: a byte lookup in the padded matrix per cell (any alphabet up to PMX_MAX_FAST_MSIZE - 1 letters).
+// FORM 1 (<= 7 letters + the pad symbol): a matrix row is 8 bytes -- one ds_read_b64 per query symbol and a v_perm_b32 by the
+//   reference symbol replace the byte lookup (fewer address adds; measured 40.0 -> 38.3 ms on cfg 5's second pass).
+// FORM 2 (<= 7 letters, ONE shared query): the two pairs of a lane group are started on the SAME query row, so a lane's row of the
+//   matrix is one register pair for both of them and ONE v_perm_b32 -- selector {symbol A | 0x0C00, symbol B | 0x0C00} -- yields both
+//   halves' scores.  The query is staged as its matrix rows (8 bytes a position), once per workgroup of four waves; the reference
+//   windows as 16-bit selectors.  The pair whose band enters the matrix further down starts early on cells outside the matrix
+//   (pad symbols: zeros that feed nothing); the processing order (pmx_sort.hip) puts pairs with nearby entry rows side by side.
+template <int LP, int FORM>
+__global__ __launch_bounds__(FORM == 2 ? 256 : 64)
 void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff, int q_shared,
                               const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff, long long n,
                               const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap, int msize,
@@ -428,34 +436,46 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
                               int QC, int RC /* staging capacity per pair, margins included */,
                               const unsigned *__restrict__ perm /* optional processing order: position -> pair */, pmx_record_t *__restrict__ out)
 {
+    constexpr bool SMALL = FORM == 1, QS = FORM == 2;
+    constexpr int NW = QS ? 4 : 1, NT = 64 * NW;             // waves, threads per workgroup
     constexpr int MG = 160;                                  // pad symbols in front of and behind every staged sequence
     __shared__ unsigned char matp[(PMX_MAX_FAST_MSIZE + 1) * (PMX_MAX_FAST_MSIZE + 1)];    // score + open as a byte; row / column msize = the pad symbol
     __shared__ unsigned char map[256];
+    __shared__ __attribute__((aligned(8))) unsigned char mrow[8 * 8];             // SMALL: row a = the 8 score bytes of query symbol a
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     const int MS1 = msize + 1;
-    for (int x = threadIdx.x; x < MS1 * MS1; x += 64) {
+    const int QMUL = SMALL ? 8 : MS1;                        // what a staged query symbol is multiplied by (the row's byte offset)
+    for (int x = threadIdx.x; x < MS1 * MS1; x += NT) {
         const int a = x / MS1, b = x - a * MS1;
         matp[x] = (a < msize && b < msize) ? (unsigned char)(gmat[a * msize + b] + open) : (unsigned char)0;      // pad: score -open
     }
-    for (int x = threadIdx.x; x < 256; x += 64) map[x] = gmap[x];
+    if ((SMALL || QS) && threadIdx.x < 64) {
+        const int a = threadIdx.x >> 3, b = threadIdx.x & 7;
+        mrow[threadIdx.x] = (a < msize && b < msize) ? (unsigned char)(gmat[a * msize + b] + open) : (unsigned char)0;
+    }
+    for (int x = threadIdx.x; x < 256; x += NT) map[x] = gmap[x];
     __syncthreads();
 
     constexpr int NG = 64 / LP, NPW = 2 * NG;                // lane groups, pairs per wave
-    const int lane = threadIdx.x, x = lane % LP, grp = lane / LP;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, x = lane % LP, grp = lane / LP;
     // per half: geometry of the pair
-    long long pairH[2]; bool haveH[2]; int qlH[2], rlH[2], d0H[2], I0H[2], J0H[2], nstH[2], cwH[2], wlenH[2]; bool hitH[2];
+    long long pairH[2], qbH[2], rbH[2]; bool haveH[2]; int qlH[2], rlH[2], d0H[2], s0H[2], I0H[2], J0H[2], nstH[2], cwH[2], wlenH[2]; bool hitH[2];
     int nsteps = 0;
-    unsigned short *qm_all = reinterpret_cast<unsigned short *>(dyn);            // [NPW][QC]: symbol * MS1, 16 bits
-    unsigned char *rm_all = dyn + (size_t)NPW * QC * 2;                           // [NPW][RC]
+    // LDS: FORM 0/1 [NPW][QC] 16-bit query symbols (x row stride), [NPW][RC] reference bytes;
+    //      FORM 2   [QC] 8-byte matrix rows of the one query, [NW][NPW][RC] 16-bit reference selectors
+    unsigned short *qm_all = reinterpret_cast<unsigned short *>(dyn);
+    unsigned char *rm_all = dyn + (size_t)NPW * QC * 2;
+    uint2 *qrows = reinterpret_cast<uint2 *>(dyn);
+    unsigned short *rs_all = reinterpret_cast<unsigned short *>(dyn + (size_t)QC * 8) + (size_t)wave * NPW * RC;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const long long pos = (long long)blockIdx.x * NPW + 2 * grp + h;
+        const long long pos = ((long long)blockIdx.x * NW + wave) * NPW + 2 * grp + h;
         haveH[h] = pos < n;
         const long long pp = perm ? (long long)perm[haveH[h] ? pos : n - 1] : (haveH[h] ? pos : n - 1);
         pairH[h] = pp;
         const long long qb = q_shared ? 0 : qoff[pp], rb = roff[pp];
         const int ql = min(q_shared ? q_shared : (int)(qoff[pp + 1] - qb), QC - 2 * MG), rl = (int)(roff[pp + 1] - rb);   // (the reference is staged by window)
-        qlH[h] = ql; rlH[h] = rl;
+        qlH[h] = ql; rlH[h] = rl; qbH[h] = qb; rbH[h] = rb;
         const int d0 = diag ? diag[pp] : 0;
         d0H[h] = d0;
         const int dlo = d0 - band, dhi = d0 + band;
@@ -472,7 +492,31 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
         // two steps early (same parity): every lane starts on pad cells, whose zeros ARE the boundary the first real cells read
         const int s0 = s_first - ((s_first + band - d0) & 1) - 2;
         int ns = s_last - s0 + 1; if (ns < 0 || s_last < 0) ns = 0;
-        nstH[h] = ns;
+        s0H[h] = s0; nstH[h] = ns;
+    }
+    if (QS) {
+        // one query row per lane for both halves: the half whose band enters the matrix further down starts that much earlier
+        const int a0 = (s0H[0] + band - d0H[0]) >> 1, a1 = (s0H[1] + band - d0H[1]) >> 1;
+        const int a = (nstH[0] && nstH[1]) ? min(a0, a1) : nstH[0] ? a0 : a1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ah = h ? a1 : a0;
+            if (nstH[h]) { s0H[h] -= 2 * (ah - a); nstH[h] += 2 * (ah - a); }
+            else s0H[h] = 2 * a - band + d0H[h];             // (no cell of its own: it rides along on the other half's rows)
+        }
+    }
+    if (QS) {                                                // the query's matrix rows, once per workgroup
+        const int ql = qlH[0];
+        for (int t = threadIdx.x; t < ql + 2 * MG; t += NT) {
+            const int i = t - MG;
+            const int sym = (i >= 0 && i < ql) ? (int)map[qbuf[i]] : msize;
+            qrows[t] = *reinterpret_cast<const uint2 *>(mrow + 8 * sym);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int s0 = s0H[h], d0 = d0H[h], ns = nstH[h], ql = qlH[h], rl = rlH[h];
+        const long long qb = qbH[h], rb = rbH[h];
         nsteps = max(nsteps, ns);
         I0H[h] = ((s0 + band - d0) >> 1) - x; J0H[h] = I0H[h] + 2 * x - band + d0;
         // Only the WINDOW of the reference the band crosses is staged: columns cw .. cw + band + steps / 2 (lane x starts at column
@@ -487,17 +531,25 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
             const long long qb2 = __shfl(qb, g2 * LP, 64), rb2 = __shfl(rb, g2 * LP, 64);
             const int ql2 = __shfl(ql, g2 * LP, 64), rl2 = __shfl(rl, g2 * LP, 64);
             const int cw2 = __shfl(cw, g2 * LP, 64), wl2 = __shfl(wlen, g2 * LP, 64);
-            unsigned short *qd = qm_all + (size_t)(2 * g2 + h) * QC;
-            unsigned char *rd = rm_all + (size_t)(2 * g2 + h) * RC;
-            if (!(q_shared && (g2 || h))) {                  // one shared query: staged once, every pair reads that copy
-                for (int t = lane; t < ql2 + 2 * MG; t += 64) {
-                    const int i = t - MG;
-                    qd[t] = (unsigned short)(((i >= 0 && i < ql2) ? (int)map[qbuf[qb2 + i]] : msize) * MS1);
+            if (!QS) {
+                unsigned short *qd = qm_all + (size_t)(2 * g2 + h) * QC;
+                if (!(q_shared && (g2 || h))) {              // one shared query: staged once, every pair reads that copy
+                    for (int t = lane; t < ql2 + 2 * MG; t += 64) {
+                        const int i = t - MG;
+                        qd[t] = (unsigned short)(((i >= 0 && i < ql2) ? (int)map[qbuf[qb2 + i]] : msize) * QMUL);
+                    }
                 }
-            }
-            for (int t = lane; t < wl2 + 16; t += 64) {
-                const int j = cw2 - 8 + t;
-                rd[t] = (unsigned char)((j >= 0 && j < rl2 && t < wl2 + 8) ? (int)map[rbuf[rb2 + j]] : msize);
+                unsigned char *rd = rm_all + (size_t)(2 * g2 + h) * RC;
+                for (int t = lane; t < wl2 + 16; t += 64) {
+                    const int j = cw2 - 8 + t;
+                    rd[t] = (unsigned char)((j >= 0 && j < rl2 && t < wl2 + 8) ? (int)map[rbuf[rb2 + j]] : msize);
+                }
+            } else {
+                unsigned short *rd = rs_all + (size_t)(2 * g2 + h) * RC;
+                for (int t = lane; t < wl2 + 16; t += 64) {
+                    const int j = cw2 - 8 + t;
+                    rd[t] = (unsigned short)(0x0C00 | ((j >= 0 && j < rl2 && t < wl2 + 8) ? (int)map[rbuf[rb2 + j]] : msize));
+                }
             }
         }
         wlenH[h] = wlen;
@@ -524,11 +576,20 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
         return r;
     };
     const b_v2s sh15 = {15, 15};
-    // best and its step, per half: 0xFFFF where H > best (one packed subtract + one shift), the step inserted under that mask
-    auto track = [&](int H, int tau) {
-        const int m = BI32((BPK(bH) - BPK(H)) >> sh15);
-        bH = bp_max3(bH, H, H);
-        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bT) : "v"(m), "s"(tau * 0x00010001), "v"(bT));
+    int signs = (int)0x80008000;
+    asm volatile("" : "+v"(signs));
+    // best and its step, per half, once per PAIR of steps (a lane's even cell and the odd cell after it): 0xFFFF where either exceeds
+    // the best (one max3, one packed subtract, one shift); what is inserted under that mask is the pair's number with bit 15 =
+    // "the odd cell is the larger" (sign of He - Ho: on a tie the even cell, the earlier one, stands).  6 instructions per two
+    // steps; one track per step was 8.
+    auto track2 = [&](int He, int Ho, int tau2) {
+        const int P = bp_max3(bH, He, Ho);
+        const int m = BI32((BPK(bH) - BPK(P)) >> sh15);
+        const int d = BI32(BPK(He) - BPK(Ho));
+        int tw;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(tw) : "v"(d), "v"(signs), "s"(tau2 * 0x00010001));      // (one SGPR per instruction)
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bT) : "v"(m), "v"(tw), "v"(bT));
+        bH = P;
     };
     // LDS read positions (element indices), clamped into the trailing pad once a pair has run past its sequences
     int qpos[2], rpos[2], qend[2], rend[2];
@@ -543,6 +604,7 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
     }
     const unsigned short *qmA = q_shared ? qm_all : qm_all + (size_t)(2 * grp) * QC, *qmB = q_shared ? qm_all : qmA + QC;
     const unsigned char *rmA = rm_all + (size_t)(2 * grp) * RC, *rmB = rmA + RC;
+    const unsigned short *rsA = rs_all + (size_t)(2 * grp) * RC, *rsB = rsA + RC;
 
     // state: everything "minus infinity" (0) except nothing -- the pad cells in front of the matrix produce the zero boundary
     int Ho1 = 0, Ho2 = 0, Ee1 = 0, Fe1 = 0;                   // H - open of the lane's previous cell and of the one before; E - ext; F - ext
@@ -550,19 +612,46 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
     //  of the SIMD already cover the two dependent LDS reads, the extra register moves cost more)
     // (the kernel is LDS-bound: a block's fifth reference symbol is the next block's first and is carried over, not read again;
     //  once a position is clamped into the trailing pads the carried symbol is a pad as well)
-    int rcarry[2] = {(int)rmA[rpos[0]], (int)rmB[rpos[1]]};
+    int rcarry[2] = {QS ? (int)rsA[rpos[0]] : (int)rmA[rpos[0]], QS ? (int)rsB[rpos[1]] : (int)rmB[rpos[1]]};
     auto fetch = [&](int (&dst)[8]) {
         int mq[2][4], mr[2][5];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { mq[0][k] = qmA[qpos[0] + k]; mq[1][k] = qmB[qpos[1] + k]; }
         mr[0][0] = rcarry[0]; mr[1][0] = rcarry[1];
 #pragma unroll
-        for (int k = 1; k < 5; ++k) { mr[0][k] = rmA[rpos[0] + k]; mr[1][k] = rmB[rpos[1] + k]; }
+        for (int k = 1; k < 5; ++k) { mr[0][k] = QS ? (int)rsA[rpos[0] + k] : (int)rmA[rpos[0] + k]; mr[1][k] = QS ? (int)rsB[rpos[1] + k] : (int)rmB[rpos[1] + k]; }
         rcarry[0] = mr[0][4]; rcarry[1] = mr[1][4];
+        if (QS) {
+            unsigned sel[5];                                 // {symbol A | 0x0C00, symbol B | 0x0C00}: bytes 1 and 3 of a score stay 0
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            dst[2 * k] = (int)matp[mq[0][k] + mr[0][k]] | ((int)matp[mq[1][k] + mr[1][k]] << 16);
-            dst[2 * k + 1] = (int)matp[mq[0][k] + mr[0][k + 1]] | ((int)matp[mq[1][k] + mr[1][k + 1]] << 16);
+            for (int c = 0; c < 5; ++c) sel[c] = ((unsigned)mr[1][c] << 16) | (unsigned)mr[0][c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint2 row = qrows[qpos[0] + k];
+                dst[2 * k] = (int)__builtin_amdgcn_perm(row.y, row.x, sel[k]);
+                dst[2 * k + 1] = (int)__builtin_amdgcn_perm(row.y, row.x, sel[k + 1]);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) rpos[h] = min(rpos[h] + 4, rend[h]);
+            qpos[0] = min(qpos[0] + 4, qend[0]);
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { mq[0][k] = qmA[qpos[0] + k]; mq[1][k] = qmB[qpos[1] + k]; }
+        if (SMALL) {
+            unsigned selA[5], selB[5];                       // the reference symbol picks its byte of the row: pair A into byte 0, pair B into byte 2
+#pragma unroll
+            for (int c = 0; c < 5; ++c) { selA[c] = (unsigned)mr[0][c] | 0x0C0C0C00u; selB[c] = ((unsigned)mr[1][c] << 16) | 0x0C000C0Cu; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint2 ra = *reinterpret_cast<const uint2 *>(mrow + mq[0][k]), rb2 = *reinterpret_cast<const uint2 *>(mrow + mq[1][k]);
+                dst[2 * k] = (int)(__builtin_amdgcn_perm(ra.y, ra.x, selA[k]) | __builtin_amdgcn_perm(rb2.y, rb2.x, selB[k]));
+                dst[2 * k + 1] = (int)(__builtin_amdgcn_perm(ra.y, ra.x, selA[k + 1]) | __builtin_amdgcn_perm(rb2.y, rb2.x, selB[k + 1]));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dst[2 * k] = (int)matp[mq[0][k] + mr[0][k]] | ((int)matp[mq[1][k] + mr[1][k]] << 16);
+                dst[2 * k + 1] = (int)matp[mq[0][k] + mr[0][k + 1]] | ((int)matp[mq[1][k] + mr[1][k + 1]] << 16);
+            }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) { qpos[h] = min(qpos[h] + 4, qend[h]); rpos[h] = min(rpos[h] + 4, rend[h]); }
@@ -572,19 +661,23 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
         fetch(sc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            int He;
             {   // even step: left from lane x - 1, up = own previous cell
                 const int lHo = below(Ho1), lEe = below(Ee1);
                 const int E = bp_max3(lEe, lHo, floorv), F = bp_max3(Fe1, Ho1, Ho1);
                 const int H = bp_max3(Ho2 + sc[2 * k], E, F);
-                track(H, t0 + 2 * k);
+                He = H;
                 Ho2 = Ho1; Ho1 = bp_subus(H, vOpen); Ee1 = bp_subus(E, vExt); Fe1 = bp_subus(F, vExt);
             }
             {   // odd step: up from lane x + 1, left = own previous cell
                 const int uHo = above(Ho1), uFe = above(Fe1);
-                int E = bp_max3(Ee1, Ho1, floorv), F = bp_max3(uFe, uHo, uHo);
+                int E = bp_max3(Ee1, Ho1, floorv);
+                const int F = bp_max3(uFe, uHo, uHo);
                 int H = bp_max3(Ho2 + sc[2 * k + 1], E, F);
-                H &= keep_odd; E &= keep_odd; F &= keep_odd;
-                track(H, t0 + 2 * k + 1);
+                // the band's last lane: its odd diagonal is outside.  H and E forced to "minus infinity" keep every lane beyond it at
+                // 0 for good (they read pad symbols, and nothing else feeds them), so the F that comes back from there is 0 unforced
+                H &= keep_odd; E &= keep_odd;
+                track2(He, H, (t0 >> 1) + k);
                 Ho2 = Ho1; Ho1 = bp_subus(H, vOpen); Ee1 = bp_subus(E, vExt); Fe1 = bp_subus(F, vExt);
             }
         }
@@ -595,7 +688,7 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
     for (int h = 0; h < 2; ++h) {
         const int hb = h ? (int)((unsigned)bH >> 16) : (bH & 0xFFFF), tb = h ? (int)((unsigned)bT >> 16) : (bT & 0xFFFF);
         BCand best = {B_NEG, 0, 0};
-        if (hb > B) { best.H = hb - B; best.i = I0H[h] + (tb >> 1); best.j = J0H[h] + (tb >> 1) + (tb & 1); }
+        if (hb > B) { best.H = hb - B; best.i = I0H[h] + (tb & 0x7FFF); best.j = J0H[h] + (tb & 0x7FFF) + (tb >> 15); }
 #pragma unroll
         for (int off = LP / 2; off >= 1; off >>= 1) {
             BCand o;
@@ -634,6 +727,8 @@ int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMat
     // local alignment inside the int16 window: two pairs per lane group, lean loop only (third form above)
     if (sw && !pmx_env("PMX_BANDED_NO_STAGING") && !pmx_env("PMX_BANDED_NO_PACKED") && open >= 0 && ext >= 0 && open + ext <= 2048 &&
         m.min + open >= 0 && m.max + open <= 255 && m.msize <= PMX_MAX_FAST_MSIZE - 1 &&
+        (long long)(max_qlen < max_rlen ? max_qlen : max_rlen) + band + 8 < 32000 &&       // a pair of steps is numbered in 15 bits
+
         (long long)(max_qlen < max_rlen ? max_qlen : max_rlen) * (m.max > 0 ? m.max : 0) + 1024 + open + ext + (m.max > 0 ? m.max : 0) < 31000) {
         const int LPp = band <= 15 ? 16 : band <= 31 ? 32 : 64, NPWp = 2 * (64 / LPp);
         // (reference: only the window the band crosses is staged -- at most band + steps / 2 + 24 symbols, steps <= 2 (qlen + band) + 4)
@@ -641,15 +736,23 @@ int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMat
         const size_t ldsp = (size_t)NPWp * ((size_t)QCp * 2 + RCp);
         if (ldsp <= 150 * 1024) {
             // neighbours in one lane group run for the longer of their two bands: process the pairs in the order of their bands' lengths
+            // one shared query over a small alphabet: FORM 2 (both pairs of a lane group on the same query rows).  Its reference windows
+            // span the query's rows whatever the reference's length (the pair that starts early walks pad columns), 16 bits a symbol
+            const int RCq = (max_qlen + 3 * band + 56 + 3) & ~3;
+            const size_t ldsq = (size_t)QCp * 8 + (size_t)4 * NPWp * RCq * 2;
+            const bool shared_rows = q_shared && m.msize <= 7 && ldsq <= 40 * 1024 && (long long)max_qlen + band + 8 < 32000 &&
+                                     !pmx_env("PMX_BANDED_NO_ROWPERM") && !pmx_env("PMX_BANDED_NO_SHARED_ROWS");
             const unsigned *perm = nullptr;
             if (sort_scratch && n >= 4096) {
-                const int rc = pmx_build_band_perm(qoff, q_shared, roff, diag, band, n, sort_scratch, &perm, stream);
+                const int rc = pmx_build_band_perm(qoff, q_shared, roff, diag, band, n, sort_scratch, &perm, stream, shared_rows);
                 if (rc < 0) return rc;
             }
-#define LPK(LP) do { if (ldsp > 48 * 1024) { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_banded_packed_kernel<LP>), 156 * 1024); if (rc) return rc; } \
-        hipLaunchKernelGGL((pmx_banded_packed_kernel<LP>), dim3((unsigned)((n + NPWp - 1) / NPWp)), dim3(64), ldsp, stream, \
-                           qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, open, ext, band, diag, QCp, RCp, perm, out); } while (0)
-            if (band <= 15) LPK(16); else if (band <= 31) LPK(32); else LPK(64);
+#define LPK(LP, FORM, NWV, LDSB, RCV) do { if ((LDSB) > 48 * 1024) { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_banded_packed_kernel<LP, FORM>), 156 * 1024); if (rc) return rc; } \
+        hipLaunchKernelGGL((pmx_banded_packed_kernel<LP, FORM>), dim3((unsigned)((n + NPWp * (NWV) - 1) / (NPWp * (NWV)))), dim3(64 * (NWV)), (LDSB), stream, \
+                           qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, open, ext, band, diag, QCp, (RCV), perm, out); } while (0)
+            if (shared_rows) { if (band <= 15) LPK(16, 2, 4, ldsq, RCq); else if (band <= 31) LPK(32, 2, 4, ldsq, RCq); else LPK(64, 2, 4, ldsq, RCq); }
+            else if (m.msize <= 7 && !pmx_env("PMX_BANDED_NO_ROWPERM")) { if (band <= 15) LPK(16, 1, 1, ldsp, RCp); else if (band <= 31) LPK(32, 1, 1, ldsp, RCp); else LPK(64, 1, 1, ldsp, RCp); }
+            else { if (band <= 15) LPK(16, 0, 1, ldsp, RCp); else if (band <= 31) LPK(32, 0, 1, ldsp, RCp); else LPK(64, 0, 1, ldsp, RCp); }
 #undef LPK
             if (kernel_name) *kernel_name = "pmx_banded_packed_kernel";
             const hipError_t e = hipGetLastError();

@@ -86,7 +86,7 @@ size_t pmx_sort_scratch_bytes(long long n);
 int pmx_build_length_perm(const int64_t *d_roff, long long n, void *scratch, const unsigned **perm_out, hipStream_t stream);
 // Processing order for banded batches: by the number of anti-diagonal steps of each pair's band (same scratch size).
 int pmx_build_band_perm(const int64_t *d_qoff, int q_shared, const int64_t *d_roff, const int32_t *d_diag, int band, long long n,
-                        void *scratch, const unsigned **perm_out, hipStream_t stream);
+                        void *scratch, const unsigned **perm_out, hipStream_t stream, bool by_entry_row = false);
 
 // Fast path: global / semi-global, score + end positions, biased packed lanes (pmx_nwsg16.hip).
 int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,

@@ -43,7 +43,7 @@ int pmx_build_length_perm(const int64_t *d_roff, long long n, void *scratch, con
 // The packed banded kernel (pmx_banded.hip) runs two pairs per lane group for max(steps A, steps B): neighbours in the processing
 // order should need about the same number of steps.  key = steps of the band inside the matrix (the kernel's own formula).
 __global__ void pmx_band_keys_kernel(const int64_t *qoff, int q_shared, const int64_t *roff, const int32_t *diag, int band, long long n,
-                                     unsigned *keys, unsigned *vals)
+                                     unsigned *keys, unsigned *vals, int by_entry_row)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -56,10 +56,14 @@ __global__ void pmx_band_keys_kernel(const int64_t *qoff, int q_shared, const in
     if (i1 >= 0 && j1 >= 0) s_last = i1 + j1;
     if (dlo > rl - 1 || dhi < -(ql - 1)) s_last = -1;
     int ns = s_last - s_first + 1; if (ns < 0) ns = 0;
-    keys[k] = (unsigned)ns; vals[k] = (unsigned)k;
+    // by_entry_row (the kernel's shared-row form: both pairs of a lane group start on one query row): first by the row where the
+    // band enters the matrix, in buckets of 16 rows, then by steps
+    const int row = dhi < 0 ? -dhi : 0;
+    keys[k] = by_entry_row ? ((unsigned)min(row >> 4, 2047) << 20) | (unsigned)min(ns, (1 << 20) - 1) : (unsigned)ns;
+    vals[k] = (unsigned)k;
 }
 int pmx_build_band_perm(const int64_t *d_qoff, int q_shared, const int64_t *d_roff, const int32_t *d_diag, int band, long long n,
-                        void *scratch, const unsigned **perm_out, hipStream_t stream)
+                        void *scratch, const unsigned **perm_out, hipStream_t stream, bool by_entry_row)
 {
     if (n <= 0 || n >= (1LL << 32)) return 1;
     unsigned *keys_in = (unsigned *)scratch, *keys_out = keys_in + n, *vals_in = keys_out + n, *perm = vals_in + n;
@@ -67,7 +71,7 @@ int pmx_build_band_perm(const int64_t *d_qoff, int q_shared, const int64_t *d_ro
     size_t temp_bytes = 0;
     (void)rocprim::radix_sort_pairs_desc(nullptr, temp_bytes, keys_in, keys_out, vals_in, perm, (size_t)n, 0, 32, stream);
     hipLaunchKernelGGL(pmx_band_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_qoff, q_shared, d_roff, d_diag, band, n,
-                       keys_in, vals_in);
+                       keys_in, vals_in, by_entry_row ? 1 : 0);
     hipError_t e = rocprim::radix_sort_pairs_desc(temp, temp_bytes, keys_in, keys_out, vals_in, perm, (size_t)n, 0, 32, stream);
     if (e != hipSuccess) return -(int)e;
     *perm_out = perm;

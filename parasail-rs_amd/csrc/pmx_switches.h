@@ -47,6 +47,8 @@ struct PmxSwitchDoc { const char *name, *kind, *what; };
     X("PMX_CIGAR_NO_OVERLAP",         "force", "batch CIGAR: sweep and walk back to back on one stream (no double buffering)") \
     X("PMX_NO_FAST_BANDED",           "force", "banded: general kernel with a band mask instead of the band-only kernel") \
     X("PMX_BANDED_NO_PACKED",         "force", "banded local alignment: the 32-bit staged kernel instead of the packed int16 kernel (two pairs per lane group)") \
+    X("PMX_BANDED_NO_ROWPERM",        "force", "packed banded kernel, alphabets of <= 7 letters: one LDS byte lookup per cell instead of the 8-byte matrix row + v_perm") \
+    X("PMX_BANDED_NO_SHARED_ROWS",    "force", "packed banded kernel, one shared query over <= 7 letters: each pair on its own query rows (forms 1 / 0) instead of both pairs of a lane group on the same rows") \
     X("PMX_BANDED_NO_STAGING",        "force", "banded: per-cell kernel (symbols from HBM) instead of the LDS-staged kernel with the lean interior loop") \
     X("PMX_GENERAL_ONE_WAVE",         "force", "general kernel: one wave per pair also for few long pairs (no pipelined sharing of a pair among the waves of a workgroup)") \
     X("PMX_GENERAL_CHUNK_BYTES",      "value", "batches through the general kernel (score fallback, score tables): bytes of boundary scratch per chunk (tests force one-pair chunks)") \

@@ -327,3 +327,51 @@ def test_banded_local_packed_kernel_edges_and_low_complexity(pkg, orc, k, monkey
     ref = al.align_batch_banded(qs, rs, k, dg)
     assert pkg.lib.pmx_last_kernel().decode() == "pmx_banded_staged_kernel"
     assert (ref == got).all()
+
+
+@pytest.mark.parametrize("k", [0, 3, 15, 16, 31, 48, 63])
+def test_banded_local_shared_query_rows(pkg, orc, k, monkeypatch):
+    """One shared query (a reused profile) over a small alphabet: the packed kernel's third form starts both pairs of a lane group on
+    the same query row (one matrix row per lane for both).  Band centres far below the main diagonal (the band enters the matrix deep
+    in the query: its lane-group partner starts early on cells outside the matrix), far above it, bands that miss the matrix,
+    references much shorter than the query, one-symbol references; an odd pair count below the sort threshold and 4 500 pairs
+    above it (processing order by entry row) -- against the banded oracle and against the per-pair-row forms."""
+    rng = np.random.default_rng(9100 + k)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    q = random_seqs(rng, 1, 380, 381)[0]
+    for n in (77, 4500):
+        rs, dg = [], []
+        for t in range(n):
+            kind = t % 7
+            if kind == 0:       # a copy of a piece of the query somewhere in a longer reference
+                a = int(rng.integers(0, 300)); body = mutate(rng, q[a:a + int(rng.integers(20, 380 - a + 1))], 0.08, 0.04)
+                pre = random_seqs(rng, 1, 0, 200)[0]; r = pre + body + random_seqs(rng, 1, 0, 100)[0]; d = len(pre) - a + int(rng.integers(-3, 4))
+            elif kind == 1:     # short reference, band entering deep in the query
+                r = random_seqs(rng, 1, 1, 60)[0]; d = -int(rng.integers(0, 380))
+            elif kind == 2:     # far above the diagonal
+                r = random_seqs(rng, 1, 300, 900)[0]; d = int(rng.integers(0, len(r)))
+            elif kind == 3:     # may miss the matrix altogether
+                r = random_seqs(rng, 1, 1, 120)[0]; d = int(rng.integers(-600, 300))
+            elif kind == 4:
+                r = q[int(rng.integers(0, 200)):]; d = -(len(q) - len(r))
+            elif kind == 5:
+                r = b"A" * int(rng.integers(1, 400)); d = int(rng.integers(-380, 400))
+            else:
+                r = random_seqs(rng, 1, 1, 3)[0]; d = int(rng.integers(-380, 3))
+            rs.append(r or b"C"); dg.append(d)
+        dg = np.array(dg, dtype=np.int32)
+        prof = pkg.Profile.new(q, False, pm)
+        al = pkg.Aligner.new().local().profile(prof).matrix(pm).gap_open(5).gap_extend(2).build()
+        got = al.align_batch_banded([], rs, k, dg)
+        assert pkg.lib.pmx_last_kernel().decode() == "pmx_banded_packed_kernel"
+        rb, ro = orc.pack(rs)
+        idx = np.arange(n) if n < 1000 else np.unique(np.concatenate([np.arange(0, n, 9), np.arange(140)]))
+        rb2, ro2 = orc.pack([rs[t] for t in idx])
+        want = orc.align_banded_batch(orc.SW, None, None, rb2, ro2, 5, 2, om, k, dg[idx], shared_query=q)
+        bad = np.nonzero((got["score"][idx] != want[:, 0]) | (got["end_query"][idx] != want[:, 1]) | (got["end_ref"][idx] != want[:, 2]))[0]
+        assert len(bad) == 0, (k, n, idx[bad[:6]], got[idx[bad[:4]]], want[bad[:4]], [(len(rs[idx[x]]), int(dg[idx[x]])) for x in bad[:4]])
+        with monkeypatch.context() as mp:
+            mp.setenv("PMX_BANDED_NO_SHARED_ROWS", "1")
+            ref = al.align_batch_banded([], rs, k, dg)
+            assert pkg.lib.pmx_last_kernel().decode() == "pmx_banded_packed_kernel"
+            assert (ref == got).all()
