@@ -754,7 +754,8 @@ int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMat
             else if (m.msize <= 7 && !pmx_env("PMX_BANDED_NO_ROWPERM")) { if (band <= 15) LPK(16, 1, 1, ldsp, RCp); else if (band <= 31) LPK(32, 1, 1, ldsp, RCp); else LPK(64, 1, 1, ldsp, RCp); }
             else { if (band <= 15) LPK(16, 0, 1, ldsp, RCp); else if (band <= 31) LPK(32, 0, 1, ldsp, RCp); else LPK(64, 0, 1, ldsp, RCp); }
 #undef LPK
-            if (kernel_name) *kernel_name = "pmx_banded_packed_kernel";
+            if (kernel_name) *kernel_name = shared_rows ? "pmx_banded_packed_kernel/shared query rows"
+                                           : (m.msize <= 7 && !pmx_env("PMX_BANDED_NO_ROWPERM")) ? "pmx_banded_packed_kernel/matrix rows" : "pmx_banded_packed_kernel";
             const hipError_t e = hipGetLastError();
             return e == hipSuccess ? 0 : -(int)e;
         }

@@ -118,6 +118,12 @@ def _suite(pkg, orc):
     cases.append(("nw/dna/banded", lambda: (rec(alb.align_batch_banded(dq[:400], dr[:400], 12)),)))
     albs = builder(dna_p, 5, 2, "sw").build()                       # banded local: the packed int16 form
     cases.append(("sw/dna/banded", lambda: (rec(albs.align_batch_banded(dq[:401], dr[:401], 12)),)))
+    bq = random_seqs(rng, 1, 260, 260)[0]                           # banded local, one shared query: both pairs of a lane group on the same query rows
+    bpre = random_seqs(rng, 300, 0, 80)
+    brs = [bpre[k] + mutate(rng, bq[k % 100:], 0.1, 0.03) for k in range(300)]
+    bdg = np.array([len(bpre[k]) - k % 100 + k % 7 - 3 for k in range(300)], dtype=np.int32)
+    albp = builder(dna_p, 5, 2, "sw").profile(pkg.Profile.new(bq, False, dna_p)).build()
+    cases.append(("sw/dna/banded shared query", lambda: (rec(albp.align_batch_banded([], brs, 20, bdg)),)))
     alt = builder(dna_p, 5, 2, "sg").use_table().build()
 
     def table():
