@@ -1275,9 +1275,17 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
     long long chunk = (long long)(chunk_bytes / per_pair) / NP * NP;
     if (chunk < NP) chunk = NP;
     if (chunk >= b.n) chunk = b.n;
-    else {                                                     // equal shares
-        const long long nch = (b.n + chunk - 1) / chunk;
-        chunk = ((b.n + nch - 1) / nch + NP - 1) / NP * NP;
+    else {
+        // Whole ROUNDS of resident workgroups per chunk: the waves of a sweep over equally long references all take the same time,
+        // so a launch of N workgroups runs for ceil(N / resident) rounds -- cfg 3 in three equal chunks of 1 042 workgroups each
+        // (512 resident) ran 5 + 3 rounds where 6.1 were needed: 45.2 -> 42.5 ms (the remainder chunk first instead of last: 42.8).
+        // Otherwise (a round does not fit a chunk): equal shares.
+        const long long round = pmx_env("PMX_STATS_EQUAL_CHUNKS") ? 0 : pmx_nwsgq_trace_round_pairs(variant, dm.d, cfg->mode, cfg->sg_flags);
+        if (round > 0 && chunk >= round) chunk = chunk / round * round;
+        else {
+            const long long nch = (b.n + chunk - 1) / chunk;
+            chunk = ((b.n + nch - 1) / nch + NP - 1) / NP * NP;
+        }
     }
     PmxBatch bc = b; bc.n = chunk;
     size_t cbytes = 0;

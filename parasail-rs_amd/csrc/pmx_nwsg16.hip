@@ -899,17 +899,21 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 // TR: the same sweep also writes the packed traceback records (R / 2 bytes per pair, lane and step; see pmx_walkp.hip) with the
 // one-instruction decision merge of pmx_nwsg16v_kernel's TRB form -- what BASELINE config 3 (statistics of a reused profile
 // against long references) runs on: the statistics are counted along the path afterwards.
-template <int G, int R, int WAVES, bool TR = false>
-__global__ __launch_bounds__(64 * WAVES)       // (<16,20,TR> takes 178 VGPRs = two waves per SIMD; forced to 168 for three it spills and is 10 % slower)
+// ENDS = false: the instance for GLOBAL alignment -- no free-end captures compiled in.  The rare capture branches sit on top of the
+// sweep's ~165 live registers: <16,20,TR> takes 178 VGPRs with them (two waves per SIMD; forced to 168 it spills and is 10 % slower)
+// and 149 without (three waves per SIMD) -- BASELINE config 3 is global.
+template <int G, int R, int WAVES, bool TR = false, bool ENDS = true>
+__global__ __launch_bounds__(64 * WAVES)
 void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
                         const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
                         long long n, const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap,
                         int msize, int open, int ext,
-                        int col_pen, int row_pen, int s1_end, int s2_end, int nb,
+                        int col_pen, int row_pen, int s1_end_arg, int s2_end_arg, int nb,
                         const unsigned *__restrict__ perm,
                         pmx_record_t *__restrict__ out, uint32_t *__restrict__ tbuf = nullptr, int Tmax = 0)
 {
     static_assert(!TR || R == 10 || R == 16 || R == 20, "trace record layouts");
+    const int s1_end = ENDS ? s1_end_arg : 0, s2_end = ENDS ? s2_end_arg : 0;
     constexpr int TD = (R + 3) / 4;               // dwords per trace record (R / 2 bytes per pair, two pairs)
     constexpr int RS = (R + 3) / 4 * 4;
     constexpr int QP = G * R;
@@ -1469,12 +1473,22 @@ static int launch_nwsgq(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     const size_t lds = (size_t)(m.msize + 1) * G * RS + 8 + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 24 +
                        (TR ? (size_t)WAVES * 64 * (PMX_QSTAGE * ((R + 3) / 4) + 1) * 4 : 0);
     if (lds > 160 * 1024) return 1;
-    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16q_kernel<G, R, WAVES, TR>)); if (rc) return rc; }
     const bool sg = mode == PMX_MODE_SG;
     const int col_pen = !(sg && (sg_flags & PMX_SG_QB)), row_pen = !(sg && (sg_flags & PMX_SG_DB));
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
+    if constexpr (TR && R == 20) {
+        if (!s1_end && !s2_end && !pmx_env("PMX_NWSGQ_ENDS_ALWAYS")) {       // no free end: the instance without captures (three waves per SIMD)
+            { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16q_kernel<G, R, WAVES, TR, false>)); if (rc) return rc; }
+            hipLaunchKernelGGL((pmx_nwsg16q_kernel<G, R, WAVES, TR, false>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream,
+                               b.qbuf, b.q_shared, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper, m.msize, open, ext,
+                               col_pen, row_pen, 0, 0, nb, b.perm, d_out, tbuf, Tmax);
+            const hipError_t e = hipGetLastError();
+            return e == hipSuccess ? 0 : -(int)e;
+        }
+    }
+    { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16q_kernel<G, R, WAVES, TR>)); if (rc) return rc; }
     hipLaunchKernelGGL((pmx_nwsg16q_kernel<G, R, WAVES, TR>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream,
                        b.qbuf, b.q_shared, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper, m.msize, open, ext,
                        col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax);
@@ -1507,6 +1521,38 @@ int pmx_nwsgq_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
         return 0;
     }
     return 1;
+}
+
+// Pairs that are resident at once (workgroups per CU x CUs x pairs per workgroup) in the sweep `variant` would launch: waves of one
+// launch over equally long references all take the same time, so a launch of N workgroups runs for ceil(N / resident) "rounds" --
+// the caller sizes its chunks in whole rounds (pmx_api.hip, stats_by_trace_shared).  0: unknown.
+template <int G, int R, bool ENDS>
+static long long nwsgq_round_pairs(size_t lds)
+{
+    static int cus = 0;
+    if (!cus) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0; cus = p.multiProcessorCount; }
+    if (pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16q_kernel<G, R, 4, true, ENDS>))) return 0;
+    int nblk = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void *>(&pmx_nwsg16q_kernel<G, R, 4, true, ENDS>), 256, lds) != hipSuccess || nblk <= 0) return 0;
+    return (long long)nblk * cus * (2 * (64 / G) * 4);
+}
+long long pmx_nwsgq_trace_round_pairs(int variant, const PmxDevMatrix &m, int mode, int sg_flags)
+{
+    const int v = variant - 30;
+    if (v < 0 || v >= 6) return 0;
+    const int G = kQShapeG[v], R = kQShapeR[v];
+    const size_t lds = (size_t)(m.msize + 1) * G * ((R + 3) / 4 * 4) + 8 + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)(2 * (64 / G) * 4) * 24 +
+                       (size_t)4 * 64 * (PMX_QSTAGE * ((R + 3) / 4) + 1) * 4;
+    const bool ends = mode == PMX_MODE_SG && (sg_flags & (PMX_SG_QE | PMX_SG_DE));
+    switch (v) {
+    case 0: return nwsgq_round_pairs<16, 10, true>(lds);
+    case 1: return nwsgq_round_pairs<16, 16, true>(lds);
+    case 2: return (ends || pmx_env("PMX_NWSGQ_ENDS_ALWAYS")) ? nwsgq_round_pairs<16, 20, true>(lds) : nwsgq_round_pairs<16, 20, false>(lds);
+    case 3: return nwsgq_round_pairs<32, 10, true>(lds);
+    case 4: return nwsgq_round_pairs<32, 16, true>(lds);
+    case 5: return nwsgq_round_pairs<64, 16, true>(lds);
+    }
+    return 0;
 }
 
 int pmx_launch_nwsgq_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
