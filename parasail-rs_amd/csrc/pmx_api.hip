@@ -1274,6 +1274,7 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
     const double per_pair = (double)tbytes / (double)b.n;
     long long chunk = (long long)(chunk_bytes / per_pair) / NP * NP;
     if (chunk < NP) chunk = NP;
+    bool by_rounds = false;
     if (chunk >= b.n) chunk = b.n;
     else {
         // Whole ROUNDS of resident workgroups per chunk: the waves of a sweep over equally long references all take the same time,
@@ -1281,7 +1282,7 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
         // (512 resident) ran 5 + 3 rounds where 6.1 were needed: 45.2 -> 42.5 ms (the remainder chunk first instead of last: 42.8).
         // Otherwise (a round does not fit a chunk): equal shares.
         const long long round = pmx_env("PMX_STATS_EQUAL_CHUNKS") ? 0 : pmx_nwsgq_trace_round_pairs(variant, dm.d, cfg->mode, cfg->sg_flags);
-        if (round > 0 && chunk >= round) chunk = chunk / round * round;
+        if (round > 0 && chunk >= round) { chunk = chunk / round * round; by_rounds = true; }
         else {
             const long long nch = (b.n + chunk - 1) / chunk;
             chunk = ((b.n + nch - 1) / nch + NP - 1) / NP * NP;
@@ -1298,7 +1299,6 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
     if (scratch_reserve(cbytes * (two ? 2 : 1), (void **)&tbuf, SCR_TRACE)) return -1;
     const bool sg = cfg->mode == PMX_MODE_SG;
     const int col_pen = !(sg && (cfg->sg_flags & PMX_SG_QB)), row_pen = !(sg && (cfg->sg_flags & PMX_SG_DB));
-    const int gsel = G == 16 ? 1 : G == 32 ? 2 : 3;
     // Sweeps of consecutive chunks go to two streams in turn (the caller's and an internal one): a chunk is a few thousand equally
     // long waves, so the tail of chunk c's launch is backfilled by chunk c + 1's workgroups instead of idling the chip.
     if (two) { HIP_OR_RET(hipEventRecord(g_tws.start, st)); HIP_OR_RET(hipStreamWaitEvent(g_tws.aux, g_tws.start, 0)); }
@@ -1313,7 +1313,17 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
         const hipStream_t sws = (two && (idx & 1)) ? g_tws.aux : st;
         if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(sws, g_tws.walk_done[idx & 1], 0));    // this buffer's previous walk is done
         if (!b.perm && upload_wait(c0 + bk.n, sws, sws == st ? 0 : 1)) return -1;                  // (host entry: this chunk's references are up)
-        int rc = pmx_launch_nwsgq_trace(variant, bk, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, out_k, tb, Tmax, sws);
+        // The remainder after the whole rounds is less than one round: its waves end the batch with the chip mostly idle, so it runs
+        // on the shape with half the rows per lane (<32,10> for <16,20>) -- twice the waves, each half as long (cfg 3: 4.8 -> 2.4 ms of tail)
+        int variant_k = variant, Tmax_k = Tmax, G_k = G, R_k = R;
+        if (by_rounds && two && bk.n < chunk && R == 20 && !pmx_env("PMX_STATS_NO_SHORT_TAIL")) {
+            int v2 = 0, T2 = 0, G2 = 0, R2 = 0; size_t tb2 = 0;
+            if (pmx_nwsgq_trace_plan(bk, dm.d, cfg->mode, cfg->open, cfg->extend, &v2, &T2, &tb2, &G2, &R2, 1) == 0 && tb2 <= cbytes) {
+                variant_k = v2; Tmax_k = T2; G_k = G2; R_k = R2;
+            }
+        }
+        const int gsel_k = G_k == 16 ? 1 : G_k == 32 ? 2 : 3;
+        int rc = pmx_launch_nwsgq_trace(variant_k, bk, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, out_k, tb, Tmax_k, sws);
         if (rc) { set_err("shared-profile traceback sweep failed (%d)", rc); return rc < 0 ? rc : -1; }
         hipStream_t ws = st;
         if (two) {
@@ -1321,7 +1331,7 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
             HIP_OR_RET(hipStreamWaitEvent(g_tws.walk, g_tws.sweep_done[idx & 1], 0));
             ws = g_tws.walk;
         }
-        rc = pmx_launch_walkp(gsel, R, bk, dm.d, cfg->mode, cfg->open, cfg->extend, Tmax, 0, st_k, row_pen, col_pen,
+        rc = pmx_launch_walkp(gsel_k, R_k, bk, dm.d, cfg->mode, cfg->open, cfg->extend, Tmax_k, 0, st_k, row_pen, col_pen,
                               tb, out_k, nullptr, nullptr, 0, nullptr, nullptr, nullptr, ws);
         if (rc) { set_err("statistics walk failed (%d)", rc); return rc < 0 ? rc : -1; }
         if (two) HIP_OR_RET(hipEventRecord(g_tws.walk_done[idx & 1], ws));

@@ -63,7 +63,7 @@ int pmx_launch_nwsgv_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m
 // Traceback with a shared query (pmx_nwsg16q_kernel<..., TR>): statistics of the profile arm are counted along the path.
 long long pmx_nwsgq_trace_round_pairs(int variant, const PmxDevMatrix &m, int mode, int sg_flags);
 int pmx_nwsgq_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
-                         int *variant, int *Tmax, size_t *trace_bytes, int *G_out, int *R_out);
+                         int *variant, int *Tmax, size_t *trace_bytes, int *G_out, int *R_out, int short_waves = 0);
 int pmx_launch_nwsgq_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                            pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream);
 

@@ -1502,7 +1502,7 @@ static int launch_nwsgq(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
 // assembly, staging flush) is shared by twice the cells -- and a record of exactly 20 bytes instead of 12 for half the cells.
 static const int kQShapeG[6] = {16, 16, 16, 32, 32, 64}, kQShapeR[6] = {10, 16, 20, 10, 16, 16};
 int pmx_nwsgq_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
-                         int *variant, int *Tmax, size_t *trace_bytes, int *G_out, int *R_out)
+                         int *variant, int *Tmax, size_t *trace_bytes, int *G_out, int *R_out, int short_waves)
 {
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
     if (!b.q_shared || !pmx_nwsgv_bias(b, m, open, ext)) return 1;
@@ -1510,7 +1510,7 @@ int pmx_nwsgq_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
     for (int v = 0; v < 6; ++v) {
         const int G = kQShapeG[v], R = kQShapeR[v];
         if (b.q_shared > G * R - 1) continue;
-        if (R == 20 && pmx_env("PMX_NWSGQ_NO_R20")) continue;
+        if (R == 20 && (short_waves || pmx_env("PMX_NWSGQ_NO_R20"))) continue;      // (short_waves: half the rows per lane = half the time per wave)
         const size_t lds = (size_t)(m.msize + 1) * G * ((R + 3) / 4 * 4) + 8 + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)(2 * (64 / G) * 4) * 24 +
                            (size_t)4 * 64 * (PMX_QSTAGE * ((R + 3) / 4) + 1) * 4;
         if (lds > 160 * 1024) continue;
