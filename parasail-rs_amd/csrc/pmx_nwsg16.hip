@@ -414,7 +414,12 @@ void pmx_nwsg16_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
 //     length or hold a letter beyond the first four marks itself in `blockflag` and leaves; the launcher then runs the LDS-
 //     profile form over exactly the marked blocks (`only_flagged`), and the walk reads the alignment of a block's rows from the
 //     same flags.
-template <int G, int R, bool TR, bool FETCH = false, bool TRB = false, bool PT = false>
+//   * ROWX (row offset, round 3): every value of effective row er is stored + er * ext, on top of the column skew that does the same
+//     for E along a row -- the vertical gap then needs no subtraction per row either: F(er) = max(F(er - 1), X(er - 1)) as it
+//     stands.  The diagonal step crosses one row: + ext in every score byte; boundary values, hand-offs and captures carry their
+//     row's offset; the decisions compare values of one row.  One instruction per row (of 7; 15.5 with the trace).  Off only for
+//     width 8's range tracking, which compares H across rows in every step.
+template <int G, int R, bool TR, bool FETCH = false, bool TRB = false, bool PT = false, bool ROWX = true>
 __global__ __launch_bounds__(64, (PT && !TR && R <= 20) ? 4 : (PT && TR) ? 3 : 1)      // (PT + TR: the staged records' LDS allows 2.75 waves per SIMD)
 void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff,
                         const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
@@ -506,8 +511,8 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         if (!ok) return;                                     // (wave-uniform)
         if (lane <= msize) {
             int v = 0;
-            if (lane < msize) { for (int k = 0; k < 4 && k < msize; ++k) v |= ((mat[k * msize + lane] + open) & 0xFF) << (8 * k); }
-            else v = (col_pen ? 0 : open) * 0x01010101;      // real row x virtual / padding column
+            if (lane < msize) { for (int k = 0; k < 4 && k < msize; ++k) v |= ((mat[k * msize + lane] + open + (ROWX ? ext : 0)) & 0xFF) << (8 * k); }
+            else v = ((col_pen ? 0 : open) + (ROWX ? ext : 0)) * 0x01010101;      // real row x virtual / padding column
             tabs[lane] = v;
         }
     }
@@ -534,8 +539,9 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     }
 
     // ---- byte profiles: logical row er = l * R + k sits at byte l * RS + k; P virtual rows on top
-    const int vrow_b = row_pen ? 0 : open;         // virtual row x real symbol
-    const int vcol_b = col_pen ? 0 : open;         // real row    x pad symbol
+    const int rx = ROWX ? ext : 0;                 // the row offset per row
+    const int vrow_b = (row_pen ? 0 : open) + rx;  // virtual row x real symbol
+    const int vcol_b = (col_pen ? 0 : open) + rx;  // real row    x pad symbol
     for (int p0 = 0; p0 < (PT ? 0 : NP); p0 += UB) {
         for (int e0 = 0; e0 < QP; e0 += 64) {
             const int er = e0 + lane;
@@ -554,11 +560,11 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
                     unsigned char *pp = lds + (p0 + u) * PROF_STRIDE + pos;
                     if (real[u]) {
                         const int q = map[raw[u]];
-                        for (int sym = 0; sym < msize; ++sym) pp[sym * QPS] = (unsigned char)(mat[q * msize + sym] + open);
+                        for (int sym = 0; sym < msize; ++sym) pp[sym * QPS] = (unsigned char)(mat[q * msize + sym] + open + rx);
                         pp[msize * QPS] = (unsigned char)vcol_b;
                     } else {
                         for (int sym = 0; sym < msize; ++sym) pp[sym * QPS] = (unsigned char)vrow_b;
-                        pp[msize * QPS] = (unsigned char)open;          // virtual x virtual: score 0
+                        pp[msize * QPS] = (unsigned char)(open + rx);   // virtual x virtual: score 0
                     }
                 }
             }
@@ -606,17 +612,24 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     int HA[R], HB[R], E[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        HA[k] = pack2(base + left_h(g * R + k, PvA), base + left_h(g * R + k, PvB));
+        const int ro = (g * R + k) * rx;             // (row offset of effective row g R + k)
+        HA[k] = pack2(base + left_h(g * R + k, PvA) + ro, base + left_h(g * R + k, PvB) + ro);
         HB[k] = HA[k]; E[k] = HA[k];
     }
     int Hout = HA[R - 1];
-    int Fout = pack2(base + open + below_f((g + 1) * R, PvA), base + open + below_f((g + 1) * R, PvB));
-    int diag0 = (g == 0) ? pack2(base, base) : pack2(base + left_h(g * R - 1, PvA), base + left_h(g * R - 1, PvB));
+    const int roF = ((g + 1) * R - 1) * rx, roD = (g * R - 1) * rx;       // the running F of row er carries (er - 1) rx; the diagonal comes from row g R - 1
+    int Fout = pack2(base + open + below_f((g + 1) * R, PvA) + roF, base + open + below_f((g + 1) * R, PvB) + roF);
+    int diag0 = (g == 0) ? pack2(base + roD, base + roD) : pack2(base + left_h(g * R - 1, PvA) + roD, base + left_h(g * R - 1, PvB) + roD);
     // row above lane 0: penalised -> H(-1, j) = -(open + j ext): a constant in the skewed X-form; free -> 0: grows by ext per column
-    int topX = row_pen ? pack2(nb + (G + 1) * ext - 2 * open, nb + (G + 1) * ext - 2 * open)
-                       : pack2(nb + (G + 1) * ext - open, nb + (G + 1) * ext - open);     // lane 0, column 0
+    int topX = row_pen ? pack2(nb + (G + 1) * ext - 2 * open - rx, nb + (G + 1) * ext - 2 * open - rx)
+                       : pack2(nb + (G + 1) * ext - open - rx, nb + (G + 1) * ext - open - rx);     // lane 0, column 0 (row -1)
     const int topStep = row_pen ? 0 : vExt;
-    int skewX = pack2((G - g + 1) * ext - open, (G - g + 1) * ext - open);   // X-form minus nb minus true value, this lane's column j0; += ext
+    const int roL = ((PT ? qlu : QP) - 1) * rx;    // row offset of the query's last row
+    // ROWX: the bias nb no longer covers the decline along the gaps (the offsets cancel it in what is STORED), but the free-end captures
+    // compare values with skew and offset taken off again: they carry a bias of their own, cb >= -(lowest true H) (scores + open >= 0,
+    // so -min <= open), taken off with nb at the end.  The host proves nb + cb + highest H < 2^15.
+    const int cb = ROWX ? 4 * open + (QP + max_rlen + 2) * ext : 0;
+    int skewX = pack2((G - g + 1) * ext - open + roL - cb, (G - g + 1) * ext - open + roL - cb);   // X-form minus nb minus cb minus true value (last row), this lane's column j0; += ext
 
     const v2s rl1 = PK(pack2(rlA - 1, rlB - 1)), rlv = PK(pack2(rlA, rlB));
     int jj = ((-g) & 0xFFFF) * 0x00010001;
@@ -667,7 +680,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const int Fe = F - vExt;
+            const int Fe = ROWX ? F : F - vExt;
             const int H = I32(n_max3f(PK(Tpre[k]), PK(E[k]), PK(Fe)));
             const int X = H - vC;
             if (TR && !TRB) {
@@ -717,7 +730,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 
         // ---- captures ----
         const v2s jv = PK(jj);
-        if (!TR && track8) {                              // (wave-uniform: the other widths pay one scalar branch per step)
+        if (!TR && !ROWX && track8) {                              // (wave-uniform: the other widths pay one scalar branch per step)
             v2s cmx = PK(Hnew[0]), cmn = PK(Hnew[0]);
 #pragma unroll
             for (int k = 1; k < R; k += 2) {
@@ -763,7 +776,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             for (int k = 0; k < R; ++k) {
                 const int er = g * R + k;
                 const int mreal = PT ? (er < qlu ? -1 : 0) : ~m_lt(PK(pack2(er, er)), Pv);
-                vals[k] = PK(Hnew[k] & mreal);
+                vals[k] = PK((Hnew[k] + pack2(cb - er * rx, cb - er * rx)) & mreal);       // rows compare without their offsets, + cb (halves stay below 2^16: no carry)
                 cm = n_max3f(cm, vals[k], vals[k]);
             }
 #pragma unroll
@@ -840,7 +853,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     const int resL = __shfl(res, lastlane, 64);
     const int browL = __shfl(I32(bestrow), lastlane, 64), browjL = __shfl(bestrowj, lastlane, 64);
     int hiA = 0, hiB = 0, loA = 0, loB = 0;                // width 8: true extremes of H over the group's cells (0 = H(-1, -1) counts)
-    if (!TR && track8) {
+    if (!TR && !ROWX && track8) {
         const int un = nb + (T - g + G) * ext - open + ext;                      // X-form of a true 0 in the form the running values ended in
         hiA = max(0, (I32(runmax) & 0xFFFF) - un); hiB = max(0, (int)((unsigned)I32(runmax) >> 16) - un);
         loA = min(0, (I32(runmin) & 0xFFFF) - un); loB = min(0, (int)((unsigned)I32(runmin) >> 16) - un);
@@ -859,10 +872,10 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
                 const int ql = (int)ptab[5 * (2 * slot + h) + 1], rl = (int)ptab[5 * (2 * slot + h) + 3];
                 const int P = PT ? 0 : QP - ql;
                 const int unsk = nb + (rl - 1 + G) * ext - open + ext;          // X-form of a true 0 at column rlen-1
-                const int corner = (int)(h ? ((unsigned)resL >> 16) : (resL & 0xFFFF)) - unsk;
+                const int corner = (int)(h ? ((unsigned)resL >> 16) : (resL & 0xFFFF)) - unsk - roL;
                 pmx_record_t rec;
                 rec.flags = 0;
-                if (!TR && track8) {
+                if (!TR && !ROWX && track8) {
                     int lo = h ? loB : loA;
                     const int hi = h ? hiB : hiA;
                     if (col_pen) lo = min(lo, -(open + (ql - 1) * ext));        // H(i, -1), H(-1, j): the boundary column and row
@@ -873,12 +886,12 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
                 else {
                     int best = -2147483647 - 1, ei = 0, ej = 0;
                     if (s2_end) {
-                        best = (int)(h ? ((unsigned)browL >> 16) : (browL & 0xFFFF)) - nb;
+                        best = (int)(h ? ((unsigned)browL >> 16) : (browL & 0xFFFF)) - nb - cb;
                         ei = ql - 1; ej = (int)(h ? ((unsigned)browjL >> 16) : (browjL & 0xFFFF));
                     }
                     if (s1_end) {
                         const unsigned key = h ? keyB : keyA;
-                        const int cv = (int)(key >> 16) - unsk;
+                        const int cv = (int)(key >> 16) - unsk - cb;
                         if (cv > best) { best = cv; ei = (int)(0xFFFFu - (key & 0xFFFFu)) - P; ej = rl - 1; }
                     }
                     rec.score = best; rec.end_query = ei; rec.end_ref = ej;
@@ -952,16 +965,21 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
     __syncthreads();
     // the shared byte profile: logical row er = l * R + k at byte l * RS + k; P virtual rows on top
     const int P = QP - qlen;
-    const int vrow_b = row_pen ? 0 : open, vcol_b = col_pen ? 0 : open;
+    // ROW OFFSET (round 3): every value of effective row er is stored + er * ext (on top of the column skew, which does the same
+    // for E along a row), so the vertical gap needs no subtraction per row either: F(er) = max(F(er - 1), X(er - 1)) as it stands.
+    // The diagonal step crosses one row: + ext in every profile byte; boundary values, hand-offs and captures carry the offset of
+    // their row; the decisions compare values of one row and do not see it.  One instruction per row (of 7, or 15.5 with the trace).
+    const int rx = ext;
+    const int vrow_b = (row_pen ? 0 : open) + rx, vcol_b = (col_pen ? 0 : open) + rx;
     for (int er = tid; er < QP; er += NT) {
         unsigned char *sc = psc + (er / R) * RS + er % R;
         if (er >= P) {
             const int q = map[qbuf[er - P]];
-            for (int sym = 0; sym < msize; ++sym) sc[sym * QPS] = (unsigned char)(mat[q * msize + sym] + open);
+            for (int sym = 0; sym < msize; ++sym) sc[sym * QPS] = (unsigned char)(mat[q * msize + sym] + open + rx);
             sc[msize * QPS] = (unsigned char)vcol_b;
         } else {
             for (int sym = 0; sym < msize; ++sym) sc[sym * QPS] = (unsigned char)vrow_b;
-            sc[msize * QPS] = (unsigned char)open;          // virtual x virtual: score 0
+            sc[msize * QPS] = (unsigned char)(open + rx);   // virtual x virtual: score 0
         }
     }
     __syncthreads();
@@ -985,14 +1003,15 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
 
     int X[R], E[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) { const int v = base + left_h(g * R + k); X[k] = pack2(v, v); E[k] = X[k]; }
+    for (int k = 0; k < R; ++k) { const int v = base + left_h(g * R + k) + (g * R + k) * rx; X[k] = pack2(v, v); E[k] = X[k]; }
     int Hout = X[R - 1];
-    int Fout; { const int v = base + open + below_f((g + 1) * R); Fout = pack2(v, v); }
-    int diag0; { const int v = (g == 0) ? base : base + left_h(g * R - 1); diag0 = pack2(v, v); }
-    int topX = row_pen ? pack2(nb + (G + 1) * ext - 2 * open, nb + (G + 1) * ext - 2 * open)
-                       : pack2(nb + (G + 1) * ext - open, nb + (G + 1) * ext - open);
+    int Fout; { const int v = base + open + below_f((g + 1) * R) + ((g + 1) * R - 1) * rx; Fout = pack2(v, v); }     // (the running F of row er carries (er - 1) * ext)
+    int diag0; { const int v = ((g == 0) ? base : base + left_h(g * R - 1)) + (g * R - 1) * rx; diag0 = pack2(v, v); }
+    int topX = row_pen ? pack2(nb + (G + 1) * ext - 2 * open - rx, nb + (G + 1) * ext - 2 * open - rx)          // (row -1)
+                       : pack2(nb + (G + 1) * ext - open - rx, nb + (G + 1) * ext - open - rx);
     const int topStep = row_pen ? 0 : vExt;
-    int skewX = pack2((G - g + 1) * ext - open, (G - g + 1) * ext - open);
+    int skewX = pack2((G - g + 1) * ext - open + (QP - 1) * rx, (G - g + 1) * ext - open + (QP - 1) * rx);    // (the last row's offset with it)
+    int cb = 0;                                      // bias of the free-end captures (see pmx_nwsg16v_kernel), set once the wave's longest reference is known
 
     const v2s rl1 = PK(pack2(rlA - 1, rlB - 1)), rlv = PK(pack2(rlA, rlB));
     int jj = ((-g) & 0xFFFF) * 0x00010001;
@@ -1028,7 +1047,7 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = k0; k < k0 + HBLK; ++k) {
-            const int Fe = F - vExt;
+            const int Fe = F;                                // (row offset: no subtraction)
             const int H = I32(n_max3f(PK(Tpre[k - k0]), PK(E[k]), PK(Fe)));
             const int Xn = H - vC;
             if (TR) {     // ND, NDL, EO, FO: the sign of each difference, inserted at its bit of the row pair's byte (see pmx_nwsg16v_kernel)
@@ -1096,7 +1115,7 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int er = g * R + k;
-                vals[k] = PK(er >= P ? X[k] : 0);
+                vals[k] = PK(er >= P ? X[k] + pack2(cb - er * rx, cb - er * rx) : 0);          // rows compare without their offsets, + cb
                 cm = n_max3f(cm, vals[k], vals[k]);
             }
 #pragma unroll
@@ -1117,6 +1136,8 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
 #pragma unroll
     for (int p = 0; p < NPW; ++p) max_rlen = max(max_rlen, (int)ptab[3 * (wave * NPW + p) + 1]);
     const int T = (max_rlen + G - 1 + 1) & ~1;
+    cb = 4 * open + (QP + max_rlen + 2) * ext;
+    skewX = pack2((G - g + 1) * ext - open + (QP - 1) * rx - cb, (G - g + 1) * ext - open + (QP - 1) * rx - cb);
     int r0a, r0b, r1a, r1b, m2a, m2b, m3a, m3b;
     fetch(0, r0a, r0b); fetch(1, r1a, r1b); fetch(2, m2a, m2b); fetch(3, m3a, m3b);
     load_scores(0, sym_of(r0a), sym_of(r0b));
@@ -1168,19 +1189,19 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
             if (pi >= 0) {
                 const int ql = qlen, rl = h ? rlB : rlA;
                 const int unsk = nb + (rl - 1 + G) * ext - open + ext;
-                const int corner = (int)(h ? ((unsigned)resL >> 16) : (resL & 0xFFFF)) - unsk;
+                const int corner = (int)(h ? ((unsigned)resL >> 16) : (resL & 0xFFFF)) - unsk - (QP - 1) * rx;
                 pmx_record_t rec;
                 rec.flags = 0;
                 if (!s1_end && !s2_end) { rec.score = corner; rec.end_query = ql - 1; rec.end_ref = rl - 1; }
                 else {
                     int best = -2147483647 - 1, ei = 0, ej = 0;
                     if (s2_end) {
-                        best = (int)(h ? ((unsigned)browL >> 16) : (browL & 0xFFFF)) - nb;
+                        best = (int)(h ? ((unsigned)browL >> 16) : (browL & 0xFFFF)) - nb - cb;
                         ei = ql - 1; ej = (int)(h ? ((unsigned)browjL >> 16) : (browjL & 0xFFFF));
                     }
                     if (s1_end) {
                         const unsigned key = h ? keyB : keyA;
-                        const int cv = (int)(key >> 16) - unsk;
+                        const int cv = (int)(key >> 16) - unsk - cb;
                         if (cv > best) { best = cv; ei = (int)(0xFFFFu - (key & 0xFFFFu)) - P; ej = rl - 1; }
                     }
                     rec.score = best; rec.end_query = ei; rec.end_ref = ej;
@@ -1218,13 +1239,14 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
     unsigned char *matT = lds;
     unsigned char *map = lds + (msize + 1) * MSTR;
     long long *ptab = reinterpret_cast<long long *>(map + 256);       // per pair: q offset, qlen, r offset, rlen, pair index
-    const int vrow_b = row_pen ? 0 : open, vcol_b = col_pen ? 0 : open;
+    const int rx = ext;                               // row offset (see ROWX at pmx_nwsg16v_kernel): every score byte + ext, no F - ext per row
+    const int vrow_b = (row_pen ? 0 : open) + rx, vcol_b = (col_pen ? 0 : open) + rx;
     const long long pair0 = (long long)blockIdx.x * NPW;
     for (int i = lane; i < (msize + 1) * MSTR; i += 64) {
         const int r = i / MSTR, q = i % MSTR;
         int v;
-        if (r < msize) v = q < msize ? gmat[q * msize + r] + open : vrow_b;
-        else v = q < msize ? vcol_b : open;                           // virtual x virtual: score 0
+        if (r < msize) v = q < msize ? gmat[q * msize + r] + open + rx : vrow_b;
+        else v = q < msize ? vcol_b : open + rx;                      // virtual x virtual: score 0
         matT[i] = (unsigned char)v;
     }
     for (int i = lane; i < 256; i += 64) map[i] = gmap[i];
@@ -1275,14 +1297,16 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 
     int X[R], E[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) { X[k] = pack2(base + left_h(g * R + k, PvA), base + left_h(g * R + k, PvB)); E[k] = X[k]; }
+    for (int k = 0; k < R; ++k) { const int ro = (g * R + k) * rx; X[k] = pack2(base + left_h(g * R + k, PvA) + ro, base + left_h(g * R + k, PvB) + ro); E[k] = X[k]; }
+    const int roF = ((g + 1) * R - 1) * rx, roD = (g * R - 1) * rx, roL = (QP - 1) * rx;
     int Hout = X[R - 1];
-    int Fout = pack2(base + open + below_f((g + 1) * R, PvA), base + open + below_f((g + 1) * R, PvB));
-    int diag0 = (g == 0) ? pack2(base, base) : pack2(base + left_h(g * R - 1, PvA), base + left_h(g * R - 1, PvB));
-    int topX = row_pen ? pack2(nb + (G + 1) * ext - 2 * open, nb + (G + 1) * ext - 2 * open)
-                       : pack2(nb + (G + 1) * ext - open, nb + (G + 1) * ext - open);
+    int Fout = pack2(base + open + below_f((g + 1) * R, PvA) + roF, base + open + below_f((g + 1) * R, PvB) + roF);
+    int diag0 = (g == 0) ? pack2(base + roD, base + roD) : pack2(base + left_h(g * R - 1, PvA) + roD, base + left_h(g * R - 1, PvB) + roD);
+    int topX = row_pen ? pack2(nb + (G + 1) * ext - 2 * open - rx, nb + (G + 1) * ext - 2 * open - rx)
+                       : pack2(nb + (G + 1) * ext - open - rx, nb + (G + 1) * ext - open - rx);
     const int topStep = row_pen ? 0 : vExt;
-    int skewX = pack2((G - g + 1) * ext - open, (G - g + 1) * ext - open);
+    int skewX = pack2((G - g + 1) * ext - open + roL, (G - g + 1) * ext - open + roL);
+    int cb = 0;                                      // bias of the free-end captures (see pmx_nwsg16v_kernel)
 
     const v2s rl1 = PK(pack2(rlA - 1, rlB - 1)), rlv = PK(pack2(rlA, rlB));
     int jj = ((-g) & 0xFFFF) * 0x00010001;
@@ -1325,7 +1349,7 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const int Fe = F - vExt;
+            const int Fe = F;                                // (row offset: no subtraction)
             const int H = I32(n_max3f(PK(Tpre[k]), PK(E[k]), PK(Fe)));
             const int Xn = H - vC;
             if (TR) {
@@ -1366,7 +1390,7 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             for (int k = 0; k < R; ++k) {
                 const int er = g * R + k;
                 const int mreal = ~m_lt(PK(pack2(er, er)), PK(pack2(PvA, PvB)));
-                vals[k] = PK(X[k] & mreal);
+                vals[k] = PK((X[k] + pack2(cb - er * rx, cb - er * rx)) & mreal);
                 cm = n_max3f(cm, vals[k], vals[k]);
             }
 #pragma unroll
@@ -1387,6 +1411,8 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
 #pragma unroll
     for (int p = 0; p < NPW; ++p) max_rlen = max(max_rlen, (int)ptab[5 * p + 3]);
     const int T = (max_rlen + G - 1 + 1) & ~1;
+    cb = 4 * open + (QP + max_rlen + 2) * ext;
+    skewX = pack2((G - g + 1) * ext - open + roL - cb, (G - g + 1) * ext - open + roL - cb);
     int r0a, r0b, r1a, r1b, m2a, m2b, m3a, m3b;
     fetch(0, r0a, r0b); fetch(1, r1a, r1b); fetch(2, m2a, m2b); fetch(3, m3a, m3b);
     load_scores(0, sym_of(r0a), sym_of(r0b));
@@ -1424,19 +1450,19 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             if (pi >= 0) {
                 const int ql = h ? qlB : qlA, rl = h ? rlB : rlA, P = h ? PvB : PvA;
                 const int unsk = nb + (rl - 1 + G) * ext - open + ext;
-                const int corner = (int)(h ? ((unsigned)resL >> 16) : (resL & 0xFFFF)) - unsk;
+                const int corner = (int)(h ? ((unsigned)resL >> 16) : (resL & 0xFFFF)) - unsk - roL;
                 pmx_record_t rec;
                 rec.flags = 0;
                 if (!s1_end && !s2_end) { rec.score = corner; rec.end_query = ql - 1; rec.end_ref = rl - 1; }
                 else {
                     int best = -2147483647 - 1, ei = 0, ej = 0;
                     if (s2_end) {
-                        best = (int)(h ? ((unsigned)browL >> 16) : (browL & 0xFFFF)) - nb;
+                        best = (int)(h ? ((unsigned)browL >> 16) : (browL & 0xFFFF)) - nb - cb;
                         ei = ql - 1; ej = (int)(h ? ((unsigned)browjL >> 16) : (browjL & 0xFFFF));
                     }
                     if (s1_end) {
                         const unsigned key = h ? keyB : keyA;
-                        const int cv = (int)(key >> 16) - unsk;
+                        const int cv = (int)(key >> 16) - unsk - cb;
                         if (cv > best) { best = cv; ei = (int)(0xFFFFu - (key & 0xFFFFu)) - P; ej = rl - 1; }
                     }
                     rec.score = best; rec.end_query = ei; rec.end_ref = ej;
@@ -1505,7 +1531,7 @@ int pmx_nwsgq_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
                          int *variant, int *Tmax, size_t *trace_bytes, int *G_out, int *R_out, int short_waves)
 {
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
-    if (!b.q_shared || !pmx_nwsgv_bias(b, m, open, ext)) return 1;
+    if (!b.q_shared || !pmx_nwsgv_bias(b, m, open, ext, 1)) return 1;
     if ((m.max > 0 ? m.max : 0) + 2 * open > 250) return 1;
     for (int v = 0; v < 6; ++v) {
         const int G = kQShapeG[v], R = kQShapeR[v];
@@ -1558,7 +1584,7 @@ long long pmx_nwsgq_trace_round_pairs(int variant, const PmxDevMatrix &m, int mo
 int pmx_launch_nwsgq_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                            pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream)
 {
-    const int nb = pmx_nwsgv_bias(b, m, open, ext);
+    const int nb = pmx_nwsgv_bias(b, m, open, ext, 1);
     if (!nb) return 1;
     switch (variant - 30) {
     case 0: return launch_nwsgq<16, 10, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
@@ -1618,6 +1644,19 @@ static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
+    if constexpr (!TR) {
+        if (b.track8) {                                     // width 8's range tracking compares H across rows: the form without the row offset
+            { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R, TR, FETCH, TRB, false, false>)); if (rc) return rc; }
+            if (b.blockflag) { const hipError_t e = hipMemsetAsync(b.blockflag, 0xFF, (size_t)blocks * sizeof(int), stream); if (e != hipSuccess) return -(int)e; }
+            g_nwsgv_pt = false;
+            hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, FETCH, TRB, false, false>), dim3((unsigned)blocks), dim3(64), lds, stream,
+                               b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
+                               m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax,
+                               b.track8, (int *)nullptr, (const int *)nullptr);
+            const hipError_t e = hipGetLastError();
+            return e == hipSuccess ? 0 : -(int)e;
+        }
+    }
     // Alphabets of <= 4 letters (+ wildcard): the perm-table form first (no LDS profile: see PT at the kernel); it marks the blocks
     // it cannot take -- query lengths that differ inside the block, a query letter beyond the first four -- and the LDS-profile form
     // below then runs over exactly those.  Needs the caller's per-block flags (PmxBatch::blockflag).
@@ -1644,20 +1683,35 @@ static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, FETCH, TRB>), dim3((unsigned)blocks), dim3(64), lds, stream,
                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                        m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax,
-                       TR ? 0 : b.track8, (int *)nullptr, only);
+                       0, (int *)nullptr, only);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
 
 // Second-generation eligibility: the profile byte score + open must fit, and the proven value range plus
 // the skew growth must fit the exact window with the bias chosen here.  Returns the bias, or 0.
-int pmx_nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext)
+int pmx_nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, int rowx)
 {
     if (pmx_env("PMX_NWSG16_GEN1")) return 0;
     if (m.msize > PMX_MAX_FAST_MSIZE - 1 || open < ext || ext < 0 || b.max_rlen > 30000) return 0;
-    const long long lo = -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
     const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);
-    const long long growth = (long long)(b.max_rlen + 2 * 64 + 4) * ext;
+    long long lo, growth;
+    if (rowx) {
+        // Row offset + column skew: a value of cell (i, j) is stored + (i + j) ext, and H(i, j) >= -(2 open + (i + j) ext) always (a
+        // gap along row -1, then one down column j): what is stored never falls more than 2 open (+ the one step of E / F / H - C /
+        // the diagonal sum below it) under the form of a true 0 -- the decline along the gaps that `lo` covers without the row offset
+        // is cancelled by the offsets.  The offsets grow the top instead: + ext per column and per row of the shape (at most twice
+        // the query's rows, 2 048).  Scores as bytes: + open + ext.
+        lo = -(3LL * open + (m.min < 0 ? -m.min : 0) + 2LL * ext);
+        growth = (long long)(b.max_rlen + 2 * 64 + 4) * ext + (long long)(2 * b.max_qlen + 64 < 2048 ? 2 * b.max_qlen + 64 : 2048) * ext;
+        if (m.max + open + ext > 255) return 0;
+        // the free-end captures: nb + cb + H in [0, 2^15), cb = 4 open + (rows + rlen + 2) ext (the kernels' own, at most)
+        const long long cbmax = 4LL * open + ((long long)(2 * b.max_qlen + 64 < 2048 ? 2 * b.max_qlen + 64 : 2048) + b.max_rlen + 2) * ext;
+        if ((1536 - lo + open) + cbmax + hi + 2LL * open + 64 >= 32767) return 0;
+    } else {
+        lo = -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));
+        growth = (long long)(b.max_rlen + 2 * 64 + 4) * ext;           // (column skew: + ext per column)
+    }
     const long long span = (hi - lo) + growth + 2LL * open + (m.max > 0 ? m.max : 0) + 2048;
     if (m.min + open < 0 || m.max + open > 255 || span >= 31743) return 0;
     return (int)(1536 - lo + open);
@@ -1669,7 +1723,7 @@ int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
                          int *variant, int *Tmax, size_t *trace_bytes)
 {
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
-    if (b.q_shared || b.perm || !pmx_nwsgv_bias(b, m, open, ext)) return 1;
+    if (b.q_shared || b.perm || !pmx_nwsgv_bias(b, m, open, ext, 1)) return 1;
     if (m.msize > 8 && m.msize < 32 && !pmx_env("PMX_NWSG16_NO_MATRIX_LOOKUP")) {   // large alphabet: the matrix-lookup kernel (1 KB of LDS)
         int G = 0;
         for (int v = 1; v < 4 && !G; ++v) if (b.max_qlen <= (8 << v) * 16 - 1) { *variant = 4 + v; G = 8 << v; }
@@ -1695,7 +1749,7 @@ int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int
 int pmx_launch_nwsgv_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                            pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream)
 {
-    const int nb = pmx_nwsgv_bias(b, m, open, ext);
+    const int nb = pmx_nwsgv_bias(b, m, open, ext, 1);
     if (!nb) return 1;
     switch (variant) {
     case 5: return launch_nwsgm<16, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
@@ -1723,7 +1777,7 @@ int pmx_launch_nwsg16(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg
     // second-generation arithmetic (skewed columns, byte profile, VOP2) whenever its window holds
     // (second generation, scores only: the row above lane 0 is a closed form, so no virtual row is needed and the
     //  query may fill all G * R rows; the first generation and the traceback walk need row -1 to exist)
-    if (const int nb = pmx_nwsgv_bias(b, m, open, ext)) {
+    if (const int nb = pmx_nwsgv_bias(b, m, open, ext, b.track8 ? 0 : 1)) {      // (width 8's range tracking: the form without the row offset)
         if (b.q_shared && !b.track8 && !pmx_env("PMX_NWSG16_NO_SHARED")) {        // profile arm: one profile per workgroup, references from HBM
 #define TRYQ(GG, RR, NAME)                                                      \
             if (q <= (GG) * (RR)) {                                         \
