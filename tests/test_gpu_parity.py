@@ -1537,3 +1537,42 @@ def test_fuzz_permtable_form_blocks_and_fallback(pkg, orc, seed):
         assert ((got["flags"] & 1) == want[:, 6]).all(), (seed, it, mode, sg, width, L)
         bad = np.nonzero(ok & ((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2])))[0]
         assert len(bad) == 0, (seed, it, mode, sg, width, L, open_, ext, match, mismatch, pkg.lib.pmx_last_kernel(), bad[:5], got[bad[:3]], want[bad[:3]])
+
+
+@pytest.mark.parametrize("gaps", [(5, 2), (3, 3), (20, 1), (11, 11)])
+def test_nwsg16_row_offset_very_negative_scores_and_every_free_end(pkg, orc, gaps):
+    """The row-offset form (every row stored + row * extend: no F - extend per row) takes the decline along the gaps out of what is
+    STORED, so the bias no longer covers it -- but the free-end captures compare values with skew and offset taken off again, and
+    the boundary values of long queries / references are very negative: long queries against short references and the other way
+    round, every mode and all 15 free-end sets, per-pair DNA (perm-table and LDS-profile forms), per-pair protein (matrix lookup:
+    2 100 pairs) and one shared protein query; gap models up to extend = open."""
+    open_, ext = gaps
+    rng = np.random.default_rng(3900 + open_ * 7 + ext)
+    dpm, dom = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    ppm, pom = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    # DNA: equal-length long queries vs short references (perm-table blocks), and ragged both ways (LDS-profile form)
+    qs = random_seqs(rng, 64, 900, 900) + random_seqs(rng, 40, 5, 40) + random_seqs(rng, 40, 400, 1000)
+    rs = random_seqs(rng, 64, 3, 60) + random_seqs(rng, 40, 800, 2500) + random_seqs(rng, 40, 1, 30)
+    for mode, sg in [(0, None)] + [(1, f) for f in range(1, 16)]:           # (no free end at all is `nw`: the builder cannot say sg with none)
+        _nwsg_case(pkg, orc, mode, sg, qs, rs, open_, ext, dpm, dom, expect_kernel=None)
+    if open_ + 11 + ext <= 255 and open_ >= 4:
+        pq = random_seqs(rng, 2100, 200, 250, AA)
+        pr = [random_seqs(rng, 1, 2, 30, AA)[0] if k % 2 else random_seqs(rng, 1, 200, 400, AA)[0] for k in range(2100)]
+        for mode, sg in ((0, None), (1, None), (1, orc.S1_END), (1, orc.S2_BEG | orc.S2_END), (1, orc.S1_BEG | orc.S1_END)):
+            _nwsg_case(pkg, orc, mode, sg, pq, pr, open_, ext, ppm, pom, expect_kernel=None)
+            assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_nwsg16m_kernel")
+        q = random_seqs(rng, 1, 700, 700, AA)[0]
+        rs2 = random_seqs(rng, 60, 2, 40, AA) + random_seqs(rng, 60, 600, 1500, AA)
+        qb, qo = orc.pack([q] * len(rs2)); rb, ro = orc.pack(rs2)
+        for mode, sg in [(0, None)] + [(1, f) for f in (1, 2, 4, 8, 3, 12, 15)]:
+            b = pkg.Aligner.new().profile(pkg.Profile.new(q, False, ppm)).matrix(ppm).gap_open(open_).gap_extend(ext).solution_width(16)
+            [b.global_, b.semi_global][mode]()
+            if mode == 1:
+                b.allow_query_gaps([t for f, t in ((orc.S1_BEG, "prefix"), (orc.S1_END, "suffix")) if sg & f])
+                b.allow_ref_gaps([t for f, t in ((orc.S2_BEG, "prefix"), (orc.S2_END, "suffix")) if sg & f])
+            got = b.build().align_batch([], rs2)
+            if ext <= 3:                                    # (extend = 11 over 700 + 1 500 symbols leaves the int16 window: general kernel)
+                assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_nwsg16q_kernel")
+            want = orc.align_batch(mode, qb, qo, rb, ro, open_, ext, pom, sg_flags=sg if sg is not None else orc.SG_ALL, bits=16)
+            bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
+            assert len(bad) == 0, (mode, sg, open_, ext, bad[:5], got[bad[:5]], want[bad[:5]])
