@@ -1554,7 +1554,7 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
         // (width 8: the same int16 kernels, which then also track the range of H for the saturation flag -- the reference's
         //  narrowest width is its fastest on a CPU; it must not be the slow road here)
         b.track8 = cfg->width == 8;
-        if (dm.d.msize <= 5 && n >= 2048 && !b.track8 && !q_shared) {       // per-block flags: lets the launcher try the perm-table form first
+        if (dm.d.msize <= 5 && n >= 2048 && !q_shared) {       // per-block flags: lets the launcher try the perm-table form first
             void *scr = nullptr;
             if (scratch_reserve(((size_t)n / 2 + 16) * sizeof(int), &scr, SCR_RETRY)) return -1;
             b.blockflag = (int *)scr;

@@ -507,6 +507,14 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             }
         }
         ok = ok && __builtin_amdgcn_ballot_w64(wild != 0) == 0 && qlu <= QP;
+        if (!TR && track8) {
+            // width 8 on this (untracked) form: only blocks whose pairs ALL saturate by their boundary alone -- a penalised boundary
+            // column or row that runs past -128: reads of >= 63 bp under 5 / 2 -- whose flag therefore needs no look at the table;
+            // every other block is left to the form that tracks the range of H
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                ok = ok && ((col_pen && open + ((int)ptab[5 * p + 1] - 1) * ext > 128) || (row_pen && open + ((int)ptab[5 * p + 3] - 1) * ext > 128));
+        }
         if (lane == 0) blockflag[blockIdx.x] = ok ? 0 : 1;
         if (!ok) return;                                     // (wave-uniform)
         if (lane <= msize) {
@@ -875,6 +883,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
                 const int corner = (int)(h ? ((unsigned)resL >> 16) : (resL & 0xFFFF)) - unsk - roL;
                 pmx_record_t rec;
                 rec.flags = 0;
+                if (!TR && PT && track8) rec.flags = PMX_FLAG_SATURATED;       // (this form only keeps blocks that saturate by their boundary)
                 if (!TR && !ROWX && track8) {
                     int lo = h ? loB : loA;
                     const int hi = h ? hiB : hiA;
@@ -1645,14 +1654,33 @@ static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
     if constexpr (!TR) {
-        if (b.track8) {                                     // width 8's range tracking compares H across rows: the form without the row offset
-            { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R, TR, FETCH, TRB, false, false>)); if (rc) return rc; }
-            if (b.blockflag) { const hipError_t e = hipMemsetAsync(b.blockflag, 0xFF, (size_t)blocks * sizeof(int), stream); if (e != hipSuccess) return -(int)e; }
+        if (b.track8) {
+            // width 8: the range of H decides the saturation flag.  Blocks whose pairs all saturate by a penalised boundary alone (most
+            // reads: -(open + 62 extend) < -128 under 5 / 2) need no tracking: they run on the perm-table form with its row offset, at
+            // width 16's speed; that launch marks the others, and the tracking form (no row offset: it compares H across rows in
+            // every step) runs over exactly those.
+            const int *only8 = nullptr;
             g_nwsgv_pt = false;
+            if constexpr (NwsgPtShape<G, R, TR>::value && !FETCH) {
+                const int nb_rowx = pmx_nwsgv_bias(b, m, open, ext, 1);      // (the caller's nb is the tracking form's: no row offset)
+                if (nb_rowx && m.msize <= 5 && b.blockflag && !b.q_shared && (col_pen || row_pen) && !pmx_env("PMX_NWSG16_NO_PERMTABLE")) {
+                    const size_t lds_pt = (size_t)NP * RP + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40 + 160 + (size_t)NP * ((G * R + 3) / 4 * 4) + 32;
+                    hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, false, TRB, true>), dim3((unsigned)blocks), dim3(64), lds_pt, stream,
+                                       b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
+                                       m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb_rowx, b.perm, d_out, tbuf, Tmax,
+                                       1, b.blockflag, (const int *)nullptr);
+                    const hipError_t e = hipGetLastError();
+                    if (e != hipSuccess) return -(int)e;
+                    only8 = b.blockflag;
+                    g_nwsgv_pt = true;
+                }
+            }
+            { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R, TR, FETCH, TRB, false, false>)); if (rc) return rc; }
+            if (!only8 && b.blockflag) { const hipError_t e = hipMemsetAsync(b.blockflag, 0xFF, (size_t)blocks * sizeof(int), stream); if (e != hipSuccess) return -(int)e; }
             hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, FETCH, TRB, false, false>), dim3((unsigned)blocks), dim3(64), lds, stream,
                                b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                                m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax,
-                               b.track8, (int *)nullptr, (const int *)nullptr);
+                               b.track8, (int *)nullptr, only8);
             const hipError_t e = hipGetLastError();
             return e == hipSuccess ? 0 : -(int)e;
         }

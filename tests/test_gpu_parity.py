@@ -1576,3 +1576,38 @@ def test_nwsg16_row_offset_very_negative_scores_and_every_free_end(pkg, orc, gap
             want = orc.align_batch(mode, qb, qo, rb, ro, open_, ext, pom, sg_flags=sg if sg is not None else orc.SG_ALL, bits=16)
             bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
             assert len(bad) == 0, (mode, sg, open_, ext, bad[:5], got[bad[:5]], want[bad[:5]])
+
+
+def test_nwsg_width8_boundary_saturated_blocks_on_the_permtable_form(pkg, orc):
+    """Width 8, equal-length reads (the perm-table form's blocks): blocks whose pairs all saturate by a penalised boundary alone
+    (-(open + (len - 1) extend) < -128) run untracked on the perm-table form, every other block -- short reads, a free boundary on the
+    side that is long, a read with a wildcard -- is marked there and tracked by the LDS-profile form.  The flag equals the oracle's
+    on every pair; unsaturated pairs carry the exact result."""
+    rng = np.random.default_rng(2370)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs, rs = [], []
+    for blk in range(300):                          # blocks of 16 pairs (the <8,R> shapes) with one read length each
+        ql = [150, 150, 40, 61, 62, 63, 64, 100][blk % 8]
+        for t in range(16):
+            q = random_seqs(rng, 1, ql, ql)[0]
+            if blk % 37 == 5 and t == 3:
+                q = q[:7] + b"N" + q[8:]
+            qs.append(q)
+            rs.append(mutate(rng, q, 0.1, 0.03) if t % 2 else random_seqs(rng, 1, 1, 170)[0])
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    idx = np.arange(len(qs))
+    seen = set()
+    for mode, sg, qg, dg in ((0, 15, None, None), (1, 2 | 8, ["suffix"], ["suffix"]), (1, 1 | 8, ["prefix"], ["suffix"]), (1, 4 | 2, ["suffix"], ["prefix"])):
+        b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).solution_width(8)
+        [b.global_, b.semi_global][mode]()
+        if qg is not None:
+            b.allow_query_gaps(qg).allow_ref_gaps(dg)
+        got = b.build().align_batch(qs, rs)
+        assert "permtable" in pkg.lib.pmx_last_kernel().decode(), pkg.lib.pmx_last_kernel()
+        want = orc.align_stats_sample(mode, idx, qb, qo, rb, ro, 5, 2, om, sg_flags=sg, bits=8)
+        bad = np.nonzero((got["flags"] & 1) != want[:, 6])[0]
+        assert len(bad) == 0, (mode, sg, bad[:5], [(len(qs[k]), len(rs[k])) for k in bad[:5]], want[bad[:5]])
+        ok = want[:, 6] == 0
+        assert (got["score"][ok] == want[ok, 0]).all() and (got["end_query"][ok] == want[ok, 1]).all() and (got["end_ref"][ok] == want[ok, 2]).all()
+        seen |= {bool(x) for x in ok}
+    assert seen == {True, False}
