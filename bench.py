@@ -50,9 +50,9 @@ VALU_MODEL = {
     "pmx_sw16q_kernel": (4.5, 3.0, "sw16q (shared profile): 4.5 VOP3/VOP3P + 3 VOP2 per 128 cells in steps that improve no lane's best (+1 in those that do)"),
     "pmx_stats16p_kernel": (30.0, 4.0, "stats16p: score arithmetic 7 + nine statistic planes moved by v_bfi_b32 under sign masks"),
     "pmx_stats16c_kernel": (17.0, 4.0, "stats16c: score arithmetic 7 + one combined statistics word per H/E/F moved by v_cndmask"),
-    "pmx_nwsg16v_kernel/packed trace": (12.25, 3.0, "nwsg16v + traceback: score 4 VOP3 + 3 VOP2, 4 packed differences + 3.5 v_bfi merges + 0.75 v_perm per 128 cells"),
-    "pmx_nwsg16q_kernel/packed trace": (12.1, 3.0, "nwsg16q + traceback: score 4 VOP3 + 3 VOP2, 4 packed differences + 3.5 v_bfi merges + 0.6 v_perm per 128 cells"),
-    "pmx_nwsg16v_kernel": (4.0, 3.0, "nwsg16v: 4 VOP3/VOP3P + 3 VOP2 per 128 cells"),
+    "pmx_nwsg16v_kernel/packed trace": (12.25, 2.0, "nwsg16v + traceback, row offset: score 4 VOP3 + 2 VOP2 (no F - extend), 4 packed differences + 3.5 v_bfi merges + 0.75 v_perm per 128 cells"),
+    "pmx_nwsg16q_kernel/packed trace": (12.1, 2.0, "nwsg16q + traceback, row offset: score 4 VOP3 + 2 VOP2 (no F - extend), 4 packed differences + 3.5 v_bfi merges + 0.6 v_perm per 128 cells"),
+    "pmx_nwsg16v_kernel": (4.0, 2.0, "nwsg16v, row offset: 4 VOP3/VOP3P + 2 VOP2 per 128 cells"),
 }
 
 
