@@ -784,7 +784,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             for (int k = 0; k < R; ++k) {
                 const int er = g * R + k;
                 const int mreal = PT ? (er < qlu ? -1 : 0) : ~m_lt(PK(pack2(er, er)), Pv);
-                vals[k] = PK((Hnew[k] + pack2(cb - er * rx, cb - er * rx)) & mreal);       // rows compare without their offsets, + cb (halves stay below 2^16: no carry)
+                vals[k] = PK((Hnew[k] + pack2((QP - er) * rx, (QP - er) * rx)) & mreal);       // rows compare in the form of the LAST row's offset (+ (QP - er) rx: inside the proven window, which holds the rows' offsets)
                 cm = n_max3f(cm, vals[k], vals[k]);
             }
 #pragma unroll
@@ -900,7 +900,7 @@ void pmx_nwsg16v_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
                     }
                     if (s1_end) {
                         const unsigned key = h ? keyB : keyA;
-                        const int cv = (int)(key >> 16) - unsk - cb;
+                        const int cv = (int)(key >> 16) - unsk - QP * rx;
                         if (cv > best) { best = cv; ei = (int)(0xFFFFu - (key & 0xFFFFu)) - P; ej = rl - 1; }
                     }
                     rec.score = best; rec.end_query = ei; rec.end_ref = ej;
@@ -1124,7 +1124,7 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int er = g * R + k;
-                vals[k] = PK(er >= P ? X[k] + pack2(cb - er * rx, cb - er * rx) : 0);          // rows compare without their offsets, + cb
+                vals[k] = PK(er >= P ? X[k] + pack2((QP - er) * rx, (QP - er) * rx) : 0);          // rows compare in the form of the last row's offset
                 cm = n_max3f(cm, vals[k], vals[k]);
             }
 #pragma unroll
@@ -1210,7 +1210,7 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
                     }
                     if (s1_end) {
                         const unsigned key = h ? keyB : keyA;
-                        const int cv = (int)(key >> 16) - unsk - cb;
+                        const int cv = (int)(key >> 16) - unsk - QP * rx;
                         if (cv > best) { best = cv; ei = (int)(0xFFFFu - (key & 0xFFFFu)) - P; ej = rl - 1; }
                     }
                     rec.score = best; rec.end_query = ei; rec.end_ref = ej;
@@ -1399,7 +1399,7 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
             for (int k = 0; k < R; ++k) {
                 const int er = g * R + k;
                 const int mreal = ~m_lt(PK(pack2(er, er)), PK(pack2(PvA, PvB)));
-                vals[k] = PK((X[k] + pack2(cb - er * rx, cb - er * rx)) & mreal);
+                vals[k] = PK((X[k] + pack2((QP - er) * rx, (QP - er) * rx)) & mreal);
                 cm = n_max3f(cm, vals[k], vals[k]);
             }
 #pragma unroll
@@ -1471,7 +1471,7 @@ void pmx_nwsg16m_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restr
                     }
                     if (s1_end) {
                         const unsigned key = h ? keyB : keyA;
-                        const int cv = (int)(key >> 16) - unsk - cb;
+                        const int cv = (int)(key >> 16) - unsk - QP * rx;
                         if (cv > best) { best = cv; ei = (int)(0xFFFFu - (key & 0xFFFFu)) - P; ej = rl - 1; }
                     }
                     rec.score = best; rec.end_query = ei; rec.end_ref = ej;
@@ -1724,6 +1724,8 @@ int pmx_nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, 
     if (m.msize > PMX_MAX_FAST_MSIZE - 1 || open < ext || ext < 0 || b.max_rlen > 30000) return 0;
     const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);
     long long lo, growth;
+    // rows of the shape that will hold the query: at most twice the query's (+ the smallest shapes' 160 / 192), at most 2 048
+    const long long rows = 2 * b.max_qlen + 64 < 192 ? 192 : 2 * b.max_qlen + 64 < 2048 ? 2 * b.max_qlen + 64 : 2048;
     if (rowx) {
         // Row offset + column skew: a value of cell (i, j) is stored + (i + j) ext, and H(i, j) >= -(2 open + (i + j) ext) always (a
         // gap along row -1, then one down column j): what is stored never falls more than 2 open (+ the one step of E / F / H - C /
@@ -1731,10 +1733,10 @@ int pmx_nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, 
         // is cancelled by the offsets.  The offsets grow the top instead: + ext per column and per row of the shape (at most twice
         // the query's rows, 2 048).  Scores as bytes: + open + ext.
         lo = -(3LL * open + (m.min < 0 ? -m.min : 0) + 2LL * ext);
-        growth = (long long)(b.max_rlen + 2 * 64 + 4) * ext + (long long)(2 * b.max_qlen + 64 < 2048 ? 2 * b.max_qlen + 64 : 2048) * ext;
+        growth = (long long)(b.max_rlen + 2 * 64 + 4) * ext + rows * ext;
         if (m.max + open + ext > 255) return 0;
         // the free-end captures: nb + cb + H in [0, 2^15), cb = 4 open + (rows + rlen + 2) ext (the kernels' own, at most)
-        const long long cbmax = 4LL * open + ((long long)(2 * b.max_qlen + 64 < 2048 ? 2 * b.max_qlen + 64 : 2048) + b.max_rlen + 2) * ext;
+        const long long cbmax = 4LL * open + (rows + b.max_rlen + 2) * ext;
         if ((1536 - lo + open) + cbmax + hi + 2LL * open + 64 >= 32767) return 0;
     } else {
         lo = -(3LL * open + (long long)(b.max_qlen + b.max_rlen + 2) * ext + (m.min < 0 ? -m.min : 0));

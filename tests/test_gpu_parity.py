@@ -1195,7 +1195,7 @@ def _seeds(default):
     return list(range(int(a), int(b)))
 
 
-@pytest.mark.parametrize("seed", _seeds([101, 102, 103]))
+@pytest.mark.parametrize("seed", _seeds([101, 102, 103, 5018]))
 def test_fuzz_fast_kernel_windows(pkg, orc, seed):
     """Randomised batches aimed at the edges of the fast kernels' exact windows: custom 4-letter matrices whose
     score + open touches 0 and 255, gap models with ext = 0 / ext = open, long references (large column skew),
