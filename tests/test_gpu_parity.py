@@ -1611,3 +1611,38 @@ def test_nwsg_width8_boundary_saturated_blocks_on_the_permtable_form(pkg, orc):
         assert (got["score"][ok] == want[ok, 0]).all() and (got["end_query"][ok] == want[ok, 1]).all() and (got["end_ref"][ok] == want[ok, 2]).all()
         seen |= {bool(x) for x in ok}
     assert seen == {True, False}
+
+
+@pytest.mark.parametrize("seed", _seeds([701, 702]))
+def test_fuzz_traceback_and_statistics_global_and_semi_global(pkg, orc, seed, monkeypatch):
+    """Random CIGAR and statistics batches over the traceback sweeps of the global / semi-global kernels (row offset, perm-table and
+    LDS-profile forms, matrix lookup, shared profile): random gap models inside the one-instruction-merge window, every free-end set,
+    lengths from 1 to 500 with long-against-short pairs both ways, DNA with wildcards, protein; CIGAR text, score, end cell and
+    matches / similar / length against the oracle's byte trace on every pair."""
+    rng = np.random.default_rng(seed)
+    monkeypatch.setenv("PMX_STATS_BY_TRACE", "1")
+    dpm, dom = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    ppm, pom = pkg.Matrix.from_name("blosum62"), orc.Matrix.from_file("tests/golden/blosum62.txt")
+    for it in range(6):
+        protein = rng.random() < 0.35
+        pm, om, alpha = (ppm, pom, AA) if protein else (dpm, dom, DNA)
+        open_ = int(rng.choice([4, 5, 11, 20] if protein else [0, 1, 3, 5, 11, 40])); ext = int(rng.choice([0, 1, 2, open_])); ext = min(ext, open_)
+        lo, hi = [(1, 30), (20, 160), (100, 260), (200, 500)][int(rng.integers(0, 4))]
+        n = int(rng.choice([3, 40, 130]))
+        qs = random_seqs(rng, n, lo, hi, alpha)
+        rs = []
+        for q in qs:
+            u = rng.random()
+            if u < 0.6: r = random_seqs(rng, 1, 0, 20, alpha)[0] + mutate(rng, q, 0.12, 0.06, alpha) + random_seqs(rng, 1, 0, 20, alpha)[0]
+            elif u < 0.8: r = random_seqs(rng, 1, 1, 12, alpha)[0]                      # long query against a few symbols
+            else: r = random_seqs(rng, 1, hi, hi + 300, alpha)[0]
+            rs.append(r or b"A")
+        if not protein:
+            for i in range(0, n, 17):
+                q = bytearray(qs[i]); q[int(rng.integers(len(q)))] = ord("N"); qs[i] = bytes(q)
+        for mode, sg in ((0, None), (1, int(rng.integers(1, 16))), (1, None)):
+            _cigar_case(pkg, orc, mode, sg, qs, rs, open_, ext, pm, om)
+            _stats_case(pkg, orc, mode, sg, qs, rs, open_, ext, pm, om)
+        if protein:
+            _stats_case(pkg, orc, 0, None, None, rs, open_, ext, pm, om, shared_query=qs[0])
+            _stats_case(pkg, orc, 1, int(rng.integers(1, 16)), None, rs, open_, ext, pm, om, shared_query=qs[0])
