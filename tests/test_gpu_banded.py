@@ -329,14 +329,15 @@ def test_banded_local_packed_kernel_edges_and_low_complexity(pkg, orc, k, monkey
     assert (ref == got).all()
 
 
+@pytest.mark.parametrize("seed", _seeds([0]))
 @pytest.mark.parametrize("k", [0, 3, 15, 16, 31, 48, 63])
-def test_banded_local_shared_query_rows(pkg, orc, k, monkeypatch):
+def test_banded_local_shared_query_rows(pkg, orc, k, seed, monkeypatch):
     """One shared query (a reused profile) over a small alphabet: the packed kernel's third form starts both pairs of a lane group on
     the same query row (one matrix row per lane for both).  Band centres far below the main diagonal (the band enters the matrix deep
     in the query: its lane-group partner starts early on cells outside the matrix), far above it, bands that miss the matrix,
     references much shorter than the query, one-symbol references; an odd pair count below the sort threshold and 4 500 pairs
     above it (processing order by entry row) -- against the banded oracle and against the per-pair-row forms."""
-    rng = np.random.default_rng(9100 + k)
+    rng = np.random.default_rng(9100 + k + 1000 * seed)
     pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
     q = random_seqs(rng, 1, 380, 381)[0]
     for n in (77, 4500):
