@@ -27,7 +27,10 @@
 
 #define LG 8                     // lanes per pair
 
-template <int G, int R>
+// ST (statistics instead of run-length ops) and SW (local alignment: the path ends where the score is used up) are template
+// parameters: the walk is VALU-bound beside the sweep it overlaps with, and each mode carries the other modes' bookkeeping otherwise
+// (score lookups and prefix sums only SW / ST need, run merging and text lengths only the op mode needs).
+template <int G, int R, bool ST, bool SW>
 __global__ __launch_bounds__(256)
 void pmx_walkp_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff, int q_shared,
                       const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff,
@@ -59,8 +62,7 @@ void pmx_walkp_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
     const long long area = pos / NPW; const int slot = (int)(pos % NPW);
     const uint32_t *tb = tbuf + (size_t)area * Tmax * (64 * D);
     const int P = (top_aligned || (blockflag && blockflag[area] == 0)) ? 0 : QP - ql;
-    const bool st = stats_out != nullptr;
-    const bool sw = mode == PMX_MODE_SW;
+    constexpr bool st = ST, sw = SW;
     const long long slot_lo = ops_off ? ops_off[pair] : qb + rb + pair - ops_base;
     const int slot_cap = ql + rl + 1;
     // ops are written from the end of the pair's slot backwards (the walk runs from the end of the alignment to its
@@ -112,11 +114,11 @@ void pmx_walkp_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
         }
         const int nib = cell ? (int)((w >> (8 * (bb & 3) + ((k & 1) ? 0 : 4))) & 0xFu) : 0;
         if (where == 0) { a = s_map[a]; bsym = s_map[bsym]; }
-        const int sc = (where == 0 && cell) ? (int)s_scores[a * msize + bsym] : 0;
+        const int sc = ((ST || SW) && where == 0 && cell) ? (int)s_scores[a * msize + bsym] : 0;
         // group masks
         const unsigned m_cell = group_bits(cell);
         const unsigned m_diag = group_bits(cell && !(nib & 8));
-        const unsigned m_eq = group_bits(a == bsym), m_sim = group_bits(sc > 0);
+        const unsigned m_eq = group_bits(a == bsym), m_sim = ST ? group_bits(sc > 0) : 0u;
         const unsigned m_eo = group_bits(cell && (nib & 2)), m_fo = group_bits(cell && (nib & 1));
         if (active) {
             if (where == 0) {
@@ -189,9 +191,12 @@ int pmx_launch_walkp(int gsel, int R, const PmxBatch &b, const PmxDevMatrix &m, 
 {
     if (b.n <= 0) return 0;
     const dim3 grid((unsigned)((b.n * LG + 255) / 256)), block(256);
-#define WALKP(GG, RR) hipLaunchKernelGGL((pmx_walkp_kernel<GG, RR>), grid, block, 0, stream, \
+#define WALKP4(GG, RR, STV, SWV) hipLaunchKernelGGL((pmx_walkp_kernel<GG, RR, STV, SWV>), grid, block, 0, stream, \
         b.qbuf, b.qoff, b.q_shared, b.rbuf, b.roff, (long long)b.n, b.perm, m.mapper, m.scores, m.msize, open, ext, mode, Tmax, top_aligned, blockflag, \
         stats_out, row_pen, col_pen, tbuf, recs, ops, ops_off, ops_base, nops, beg, textlen)
+#define WALKP(GG, RR) do { const bool st_ = stats_out != nullptr, sw_ = mode == PMX_MODE_SW; \
+        if (st_) { if (sw_) WALKP4(GG, RR, true, true); else WALKP4(GG, RR, true, false); } \
+        else { if (sw_) WALKP4(GG, RR, false, true); else WALKP4(GG, RR, false, false); } } while (0)
     if (R == 16) {
         switch (gsel) {
         case 0: WALKP(8, 16); break;
@@ -210,6 +215,7 @@ int pmx_launch_walkp(int gsel, int R, const PmxBatch &b, const PmxDevMatrix &m, 
         }
     } else return 1;
 #undef WALKP
+#undef WALKP4
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }
