@@ -136,12 +136,38 @@ void pmx_walkp_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
                 }
                 const unsigned cm = (1u << c) - 1u;
                 if (st) { nM += __builtin_popcount(m_eq & cm); nS += __builtin_popcount(m_sim & cm); }
-                unsigned bits = m_eq; int left = c;
-                while (left > 0) {
-                    const unsigned b0 = bits & 1u;
-                    int run = __builtin_ctz((b0 ? ~bits : bits) | (1u << left));
-                    add_run(b0 ? OP_EQ : OP_X, run);
-                    bits >>= run; left -= run;
+                if (ST) nL += c;
+                else if (c > 0) {
+                    // The window's = / X runs leave in ONE pass, a lane per run (no loop over the runs: eight pairs walk in one wave, and
+                    // the loop ran for the pair with the most runs).  Run starts: cell 0 and every cell that differs from the one before.
+                    // The pending run (cur_op, cur_len) absorbs run 0 if it has the same op and leaves as soon as another run follows;
+                    // the runs between the first and the last are complete (at most 8 cells: one digit each); the last one is the new
+                    // pending run.  All counts are group-uniform; only the stores are per lane.
+                    const unsigned cmw = (1u << c) - 1u, w = m_eq & cmw;
+                    const unsigned starts = ((w ^ (w << 1)) & cmw) | 1u;
+                    const int nr = __builtin_popcount(starts);
+                    const uint32_t op0 = (w & 1u) ? OP_EQ : OP_X;
+                    const bool same = cur_len != 0 && op0 == cur_op;
+                    const unsigned rest = starts & ~1u;
+                    const int s1 = rest ? __builtin_ctz(rest) : c;                 // end of run 0
+                    const int slast = 31 - __builtin_clz(starts);                  // start of the last run
+                    const uint32_t lenA = same ? cur_len + (uint32_t)s1 : cur_len;
+                    const bool emitA = same ? nr >= 2 : cur_len != 0;
+                    int basec = cnt;
+                    if (emitA) { ++basec; if (l == 0) o_end[-basec] = (lenA << 4) | cur_op; tlen += digits(lenA) + 1; }
+                    const int r0 = same ? 1 : 0;
+                    const int nfull = nr - 1 - r0 > 0 ? nr - 1 - r0 : 0;
+                    if ((starts >> l) & 1u) {
+                        const int r = __builtin_popcount(starts & ((1u << l) - 1u));
+                        if (r >= r0 && r <= nr - 2) {
+                            const unsigned nx = starts >> (l + 1);                  // (not 0: a later run exists)
+                            const int e = l + 1 + __builtin_ctz(nx | 0x100u);
+                            o_end[-(basec + (r - r0) + 1)] = ((uint32_t)(e - l) << 4) | (((w >> l) & 1u) ? OP_EQ : OP_X);
+                        }
+                    }
+                    tlen += 2 * nfull; cnt = basec + nfull;
+                    if (nr == 1 && same) cur_len = lenA;
+                    else { cur_op = ((w >> (c - 1)) & 1u) ? OP_EQ : OP_X; cur_len = (uint32_t)(c - slast); }
                 }
                 i -= c; j -= c;
                 if (c < LG) {
