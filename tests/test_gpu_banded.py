@@ -376,3 +376,38 @@ def test_banded_local_shared_query_rows(pkg, orc, k, seed, monkeypatch):
             ref = al.align_batch_banded([], rs, k, dg)
             assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_banded_packed_kernel")
             assert (ref == got).all()
+
+
+@pytest.mark.parametrize("letters", [b"ACGTN", b"ACGTNR", b"ACGTNRY"])
+def test_banded_local_row_lookup_forms_on_wider_alphabets(pkg, orc, letters):
+    """The packed kernel's matrix-row forms read a query symbol's scores as 8 bytes and pick one with `v_perm_b32`: alphabets of 5 and 6
+    letters (+ wildcard = 6 and 7 symbols, selectors into the second source register, the pad symbol last) take them, 7 letters
+    (8 symbols) the byte-lookup form -- per-pair queries and one shared query, against the banded oracle."""
+    rng = np.random.default_rng(9300 + len(letters))
+    alpha = np.frombuffer(letters, dtype=np.uint8)
+    pm, om = pkg.Matrix.create(letters, 3, -2), orc.Matrix.create(letters.decode(), 3, -2)
+    q = random_seqs(rng, 1, 300, 301, alpha)[0]
+    rs, dg = [], []
+    for t in range(4200):
+        a = int(rng.integers(0, 200))
+        pre = random_seqs(rng, 1, 0, 120, alpha)[0]
+        rs.append(pre + mutate(rng, q[a:a + int(rng.integers(30, 100))], 0.1, 0.04, alpha) + random_seqs(rng, 1, 0, 60, alpha)[0])
+        dg.append(len(pre) - a + int(rng.integers(-4, 5)))
+    dg = np.array(dg, dtype=np.int32)
+    idx = np.arange(0, len(rs), 11)
+    rb2, ro2 = orc.pack([rs[t] for t in idx])
+    expect = {5: "/shared query rows", 6: "/shared query rows", 7: ""}[len(letters)]
+    for band in (12, 40):
+        al = pkg.Aligner.new().local().profile(pkg.Profile.new(q, False, pm)).matrix(pm).gap_open(4).gap_extend(1).build()
+        got = al.align_batch_banded([], rs, band, dg)
+        assert pkg.lib.pmx_last_kernel().decode() == "pmx_banded_packed_kernel" + expect, pkg.lib.pmx_last_kernel()
+        want = orc.align_banded_batch(orc.SW, None, None, rb2, ro2, 4, 1, om, band, dg[idx], shared_query=q)
+        assert (got["score"][idx] == want[:, 0]).all() and (got["end_query"][idx] == want[:, 1]).all() and (got["end_ref"][idx] == want[:, 2]).all()
+        # per-pair queries: the per-pair row form
+        qs = [q[int(rng.integers(0, 50)):] for _ in idx]
+        al2 = pkg.Aligner.new().local().matrix(pm).gap_open(4).gap_extend(1).build()
+        got2 = al2.align_batch_banded(qs, [rs[t] for t in idx], band, dg[idx])
+        assert pkg.lib.pmx_last_kernel().decode() == "pmx_banded_packed_kernel" + ("/matrix rows" if len(letters) < 7 else ""), pkg.lib.pmx_last_kernel()
+        qb, qo = orc.pack(qs)
+        want2 = orc.align_banded_batch(orc.SW, qb, qo, rb2, ro2, 4, 1, om, band, dg[idx])
+        assert (got2["score"] == want2[:, 0]).all() and (got2["end_query"] == want2[:, 1]).all() and (got2["end_ref"] == want2[:, 2]).all()
