@@ -189,8 +189,14 @@ def test_batches_outside_every_packed_window_take_the_band_kernel(pkg, orc, mode
 
 
 def _seeds(default):
+    """PMX_FUZZ_SEEDS=a:b (or a comma list) widens the seed list for soak runs"""
     spec = os.environ.get("PMX_FUZZ_SEEDS")
-    return [int(x) for x in spec.split(",")] if spec else default
+    if not spec:
+        return default
+    if ":" in spec:
+        a, b = spec.split(":")
+        return list(range(int(a), int(b)))
+    return [int(x) for x in spec.split(",")]
 
 
 @pytest.mark.parametrize("seed", _seeds([301, 302, 303]))
