@@ -138,6 +138,14 @@ def pmc_summary(config, kernel):
             per_step = float(d.get("launches_per_step", 1.0))       # chunked pipelines launch the sweep several times per step
             out["traffic"] = int((2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024 * per_step)
             out["launches_per_step"] = per_step
+        if "SQ_INSTS_VALU" in d and "GRBM_GUI_ACTIVE" in d:
+            # measured issue rate of the dominant kernel (serialised launches): GRBM_GUI_ACTIVE sums the 8 XCDs, 1 024 SIMDs issue
+            cyc = d["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
+            valu = d["SQ_INSTS_VALU"]["mean_per_launch"]
+            out["valu_issue"] = {"valu_instructions_per_launch": int(valu), "cycles_per_launch": int(cyc),
+                                 "cycles_per_valu_instruction_per_simd": round(cyc / max(1.0, valu / 1024.0), 3),
+                                 "note": "a VOP3 / VOP3P wave64 instruction occupies its SIMD for 4 cycles: at ~4 the kernel is bound by "
+                                         "VALU issue and only fewer instructions make it faster"}
         if "SQ_LDS_BANK_CONFLICT" in d and "SQ_LDS_IDX_ACTIVE" in d:
             out["lds_bank_conflict"] = {"conflict_cycles": int(d["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"]),
                                         "lds_active_cycles": int(d["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"]),
@@ -685,6 +693,8 @@ def run_config(env, config, steps, warmup, scaling, pairs, cpu_legs=True, deferr
         if peak:
             line["roofline_valu"] = {"bound": "valu", "achieved": round(kern_gcups, 2), "peak": round(peak, 1), "unit": "GCUPS",
                                      "frac": round(kern_gcups / peak, 4), "model": model}
+            if pmc and "valu_issue" in pmc:
+                line["roofline_valu"]["measured"] = dict(pmc["valu_issue"], source=pmc["source"])
         if multi and world == 1:
             # rehearsal of the exchange path with one rank (PMX_BENCH_FORCE_DIST): what rank 0 gathered must be what it computed
             line["exchange_check"] = w.check_exchange(env.last_gather) if hasattr(w, "check_exchange") else \
