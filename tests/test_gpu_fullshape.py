@@ -423,3 +423,42 @@ def test_profile_host_entry_uploads_behind_the_kernels(pkg, orc):
     got = al0.align_batch_packed(None, None, rbuf, roff)
     want0 = orc.align_stats_sample(orc.SW, idx, None, None, rbuf, roff, 11, 1, om, shared_query=q)
     assert (got["score"][idx] == want0[:, 0]).all() and (got["end_ref"][idx] == want0[:, 2]).all()
+
+
+def test_bench_default_line_carries_every_config():
+    """The driver's command (`python bench.py --gpus 1 --steps K --warmup W`) in a fresh child process: ONE JSON line with the
+    contract's keys, config 2 as `value`, `roofline` (algorithmic bytes over the kernel's time, measured traffic from the committed
+    PMC summary or null), `roofline_valu`, `cpu_baseline` whose sampled results equal the GPU's -- and BASELINE configs 3, 4 and 5
+    under `configs`, each with the same objects.  The host-side legs run after every GPU measurement."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PMX_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:3]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1 and line["unit"] == "GCUPS" and line["vs_baseline"] is None
+    assert line["value"] > 1000 and "cfg2" in line["config"]["workload"] and "model" not in line["config"]
+
+    def check(rec, name):
+        r = rec["roofline"]
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in r, (name, key)
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+        assert r["traffic"] is None or r["traffic"] > 0
+        assert rec["roofline_valu"]["bound"] == "valu" and 0 < rec["roofline_valu"]["frac"] < 1.2
+        c = rec["cpu_baseline"]
+        assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"] and c["agrees_with_gpu"] is True, (name, c)
+        assert rec["value"] > 100 * c["value"] / max(1, c["cores"]), name
+    check(line, "cfg2")
+    assert sorted(line["configs"]) == ["3", "4", "5"]
+    for k, rec in line["configs"].items():
+        assert rec["value"] > 500 and rec["ms_per_step"] > 0 and ("cfg%s" % k) in rec["config"]["workload"], k
+        check(rec, "cfg" + k)
+    assert line["configs"]["5"]["banded_sw"]["ms"] > 0
