@@ -1282,7 +1282,10 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
         // (512 resident) ran 5 + 3 rounds where 6.1 were needed: 45.2 -> 42.5 ms (the remainder chunk first instead of last: 42.8).
         // Otherwise (a round does not fit a chunk): equal shares.
         const long long round = pmx_env("PMX_STATS_EQUAL_CHUNKS") ? 0 : pmx_nwsgq_trace_round_pairs(variant, dm.d, cfg->mode, cfg->sg_flags);
-        if (round > 0 && chunk >= round) { chunk = chunk / round * round; by_rounds = true; }
+        if (round > 0 && chunk >= round) {
+            chunk = chunk / round * round; by_rounds = true;
+            if (g_upload) chunk = round;                       // (host entry: the references arrive in slices -- a sweep starts as soon as ONE round's worth is up)
+        }
         else {
             const long long nch = (b.n + chunk - 1) / chunk;
             chunk = ((b.n + nch - 1) / nch + NP - 1) / NP * NP;
