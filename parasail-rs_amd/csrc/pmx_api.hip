@@ -1922,10 +1922,12 @@ static int banded_device(const pmx_config_t *cfg, int64_t n, const uint8_t *d_qb
     if (!guard.ok) { set_err("stream guard failed"); return -1; }
     pmx_config_t c = *cfg; c.width = 32;                       // 32-bit lanes: no saturation inside a band
     const char *kname = "pmx_banded_kernel";
-    void *sort_scr = nullptr;
-    if (c.mode == PMX_MODE_SW && n >= 4096 && n < (1LL << 32) && scratch_reserve(pmx_sort_scratch_bytes(n), &sort_scr, SCR_SORT)) return -1;
+    void *sort_scr = nullptr, *retry_scr = nullptr;
+    if (n >= 4096 && n < (1LL << 32) && scratch_reserve(pmx_sort_scratch_bytes(n), &sort_scr, SCR_SORT)) return -1;
+    if (n < (1LL << 31) && scratch_reserve(((size_t)n + 1) * sizeof(unsigned), &retry_scr, SCR_RETRY)) return -1;
     const int rcb = pmx_launch_banded(c.mode, c.sg_flags, c.open, c.extend, dm.d, n, d_qbuf, d_qoff, q_shared, d_rbuf, d_roff,
-                                      max_qlen, max_rlen, band, d_diag, d_out, (hipStream_t)stream, &kname, sort_scr);
+                                      max_qlen, max_rlen, band, d_diag, d_out, (hipStream_t)stream, &kname, sort_scr,
+                                      retry_scr ? (unsigned *)retry_scr + 1 : nullptr, (int *)retry_scr);
     if (rcb < 0) { set_err("banded kernel launch failed: %s", hipGetErrorString((hipError_t)(-rcb))); return rcb; }
     if (rcb == 0) { g_last_kernel = kname; return 0; }
     const int rc = general_batch(&c, dm, n, d_qbuf, d_qoff, q_shared, d_rbuf, d_roff, max_rlen, band, d_diag, false, d_out, nullptr,

@@ -46,6 +46,7 @@ void pmx_banded_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
                        const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff, long long n,
                        const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap, int msize,
                        int mode, int sg_flags, int open, int ext, int band, const int32_t *__restrict__ diag,
+                       const unsigned *__restrict__ list /* optional: the pairs to work on ... */, const int *__restrict__ n_dev /* ... and their count (device) */,
                        pmx_record_t *__restrict__ out)
 {
     __shared__ int16_t mat[PMX_MAX_FAST_MSIZE * PMX_MAX_FAST_MSIZE];
@@ -56,9 +57,13 @@ void pmx_banded_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
 
     constexpr int NPW = 64 / LP;
     const int lane = threadIdx.x, x = lane % LP;
-    const long long pair = (long long)blockIdx.x * NPW + lane / LP;
-    const bool have = pair < n;
-    const long long pp = have ? pair : n - 1;
+    // list form (pairs handed back by pmx_bstrip_kernel): a fixed grid walks the device-side list; otherwise one pass
+    const long long nitems = list ? (long long)*n_dev : n;
+    for (long long base = (long long)blockIdx.x * NPW; base < nitems; base += (long long)gridDim.x * NPW) {
+    const long long item = base + lane / LP;
+    const bool have = item < nitems;
+    const long long pair = list ? (long long)list[have ? item : nitems - 1] : item;
+    const long long pp = have ? pair : (list ? pair : n - 1);
     const long long qb = q_shared ? 0 : qoff[pp], rb = roff[pp];
     const int ql = q_shared ? q_shared : (int)(qoff[pp + 1] - qb), rl = (int)(roff[pp + 1] - rb);
     const uint8_t *q = qbuf + qb, *r = rbuf + rb;
@@ -167,6 +172,19 @@ void pmx_banded_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
         }
         out[pair] = rec;
     }
+    }
+}
+
+// pairs the band-strip kernel (pmx_bstrip.hip) handed back: a fixed grid over the device-side list
+void pmx_banded_retry(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,
+                      const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
+                      int band, const int32_t *diag, const unsigned *list, const int *count, pmx_record_t *out, hipStream_t stream)
+{
+    const unsigned blocks = (unsigned)std::min<long long>(n, 2048);
+#define LBR(LP) hipLaunchKernelGGL((pmx_banded_kernel<LP>), dim3(blocks), dim3(64), 0, stream, \
+                                   qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, mode, sg_flags, open, ext, band, diag, list, count, out)
+    if (band <= 15) LBR(16); else if (band <= 31) LBR(32); else LBR(64);
+#undef LBR
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -712,10 +730,16 @@ void pmx_banded_packed_kernel(const uint8_t *__restrict__ qbuf, const int64_t *_
 int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,
                       const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
                       int max_qlen, int max_rlen, int band, const int32_t *diag, pmx_record_t *out, hipStream_t stream,
-                      const char **kernel_name, void *sort_scratch)
+                      const char **kernel_name, void *sort_scratch, unsigned *retry_list, int *retry_count)
 {
     if (n <= 0) return 0;
     if (pmx_env("PMX_NO_FAST_BANDED")) return 1;
+    // the band-strip kernel (band coordinates, packed int16, C offsets per lane) where its window holds
+    if (!pmx_env("PMX_BANDED_NO_STAGING") && !pmx_env("PMX_BANDED_NO_PACKED")) {
+        const int rcs = pmx_launch_bstrip(mode, sg_flags, open, ext, m, n, qbuf, qoff, q_shared, rbuf, roff, max_qlen, max_rlen, band, diag, out, stream,
+                                          kernel_name, sort_scratch, retry_list, retry_count);
+        if (rcs <= 0) return rcs;
+    }
     if (m.msize > PMX_MAX_FAST_MSIZE || band > 63) return 1;       // wider bands: the general kernel masks instead
     const int LPs = band <= 15 ? 16 : band <= 31 ? 32 : 64, NPW = 64 / LPs;
     const int QC = (max_qlen + 3) & ~3, RC = (max_rlen + 3) & ~3;
@@ -761,7 +785,7 @@ int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMat
         }
     }
 #define LB(LP) hipLaunchKernelGGL((pmx_banded_kernel<LP>), dim3((unsigned)((n + 64 / LP - 1) / (64 / LP))), dim3(64), 0, stream, \
-                                  qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, mode, sg_flags, open, ext, band, diag, out)
+                                  qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, mode, sg_flags, open, ext, band, diag, nullptr, nullptr, out)
 #define LS(LP, SWF) hipLaunchKernelGGL((pmx_banded_staged_kernel<LP, SWF>), dim3((unsigned)((n + 64 / LP - 1) / (64 / LP))), dim3(64), lds, stream, \
                                   qbuf, qoff, q_shared, rbuf, roff, n, m.scores, m.mapper, m.msize, mode, sg_flags, open, ext, band, diag, QC, RC, out)
     if (staged) {
