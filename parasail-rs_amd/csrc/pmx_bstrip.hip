@@ -109,13 +109,14 @@ __device__ __forceinline__ void s_init_of(const SGeo &p, const SConst &k, int d,
     fn = col_pen ? hx + Cg : hx;
 }
 
-template <int G, int C, int MODEV /* 0: nw / sg, one skew; 1: nw / sg, double skew; 2: sw */, int EPG /* leading cells with a guard */>
+template <int G, int C, int MODEV /* 0: nw / sg, one skew; 1: nw / sg, double skew; 2: sw */,
+          int EPG /* > 0: that many leading cells carry a guard of their own; < 0: the first -EPG cells are ONE guarded block (the band starts at cell -EPG of the first live lane) */>
 __global__ __launch_bounds__(64)
 void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff, int q_shared,
                        const uint8_t *__restrict__ rbuf, const int64_t *__restrict__ roff, long long n,
                        const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap, int msize,
                        SConst k, const int32_t *__restrict__ diag, const unsigned *__restrict__ perm,
-                       int RC, int QC /* bytes per lane group: reference selectors, query letters */,
+                       int RC, int QC /* bytes per lane group: reference selectors, query letters (one shared query: QC bytes once) */,
                        unsigned *__restrict__ retry_list, int *__restrict__ retry_count, pmx_record_t *__restrict__ out)
 {
     constexpr bool SW = MODEV == 2;
@@ -129,7 +130,7 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
     __shared__ unsigned char map[256];
     __shared__ uint2 tab2[36];                       // (letter a of pair A, letter b of pair B) -> the two score dwords; 5 = no row
     __shared__ int gwild[NP];
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];   // [NG][RC] reference selectors, [NG][QC] query letters
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];   // [NG][RC] reference selectors, [NG][QC] query letters ([QC]: one shared query)
 
     const int lane = threadIdx.x;
     const int l16 = lane & 15, g = l16 / SUBG, sub = l16 % SUBG, grp = (lane >> 4) * SUBG + sub;
@@ -204,6 +205,21 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
                 if (t < RC) rsg[t] = (unsigned char)(ca | (cb << 4));
             }
         }
+        if (q_shared) {
+            // one shared query: its letters once per wave (index = row + PADF), every pair reads from its own first row on
+            for (int x0 = lane; x0 < QC; x0 += 64 * SB) {
+                int qa[SB];
+#pragma unroll
+                for (int y = 0; y < SB; ++y) { const int x = x0 + y * 64, i = x - PADF; qa[y] = (i >= 0 && i < q_shared) ? (int)qbuf[i] : -1; }
+#pragma unroll
+                for (int y = 0; y < SB; ++y) {
+                    const int x = x0 + y * 64;
+                    int a = 5;
+                    if (qa[y] >= 0) { a = map[qa[y]]; if (a > 4) a = 4; }
+                    if (x < QC) qs_all[x] = (unsigned char)a;
+                }
+            }
+        } else
         for (int x0 = g; x0 < QC; x0 += G * SB) {
             int qa[SB], qb[SB];
 #pragma unroll
@@ -274,6 +290,7 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
     // ---- streams ----
     const unsigned char *rs = rs_all + (size_t)grp * RC + g * (C - 1);        // position of (u, c): rs[u + c]
     const unsigned char *qs = qs_all + (size_t)grp * QC + (PADF - g);          // row of wave step u: qs[u]
+    const unsigned char *qsA = qs_all + P[0].i_s + (PADF - g), *qsB = qs_all + P[1].i_s + (PADF - g);   // one shared query: the pairs' own rows
     int S[C + U];
     auto sel_of = [&](int byte) -> int {             // (A nibble, B nibble) -> {A, 0x0C, B, 0x0C}
         return (((byte << 12) | byte) & 0x000F000F) | 0x0C000C00;
@@ -290,15 +307,31 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
     // captures
     int corner[2] = {S_NEG, S_NEG};
     int browH[2] = {S_NEG, S_NEG}, browJ[2] = {0, 0}, bcolH[2] = {S_NEG, S_NEG}, bcolI[2] = {0, 0};
-    int bestT[2] = {0, 0}, bestJ[2] = {0x7FFFFFFF, 0x7FFFFFFF}, bestI[2] = {0, 0};     // sw: true score, column, row
     int best = SW ? (k.bias - Cg) * 0x00010001 : 0;  // sw: the lane's best in the X form of its current row
+    int bestrow = 0;                                 // sw: the row (relative, per half) that saved it
+    int fake = -1;                                   // sw: halves whose `best` is not a score this lane has seen (the initial zero; a bound taken over from the group)
+    int Hsave[SW ? C : 1];                           // sw: that row's strip
+#pragma unroll
+    for (int c = 0; c < (SW ? C : 1); ++c) Hsave[c] = 0;
     const int tauM[2] = {(!P[0].miss && P[0].i_s + P[0].rows == P[0].ql) ? P[0].ql - 1 - P[0].i_s : -0x40000000,
                          (!P[1].miss && P[1].i_s + P[1].rows == P[1].ql) ? P[1].ql - 1 - P[1].i_s : -0x40000000};
     // last column: the lane's cell index of column rl - 1 in row tau is lc0 - tau
     const int lc0[2] = {P[0].rl - 1 - P[0].i_s - P[0].j0 - (g * C - eL), P[1].rl - 1 - P[1].i_s - P[1].j0 - (g * C - eL)};
 
-    uint2 tabN = tab2[qs[0]];
-    int qbN = qs[1];
+    // (one shared query: tab2[a].x and tab2[6 b].y are the single letters' tables)
+    // rows in which this lane may have something to capture (corner / last row: tauM; last column: C rows ending at lc0): one range
+    int evLo = 0x7FFFFFFF, evHi = -1;
+    if (!SW) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (tauM[h] >= 0) { evLo = min(evLo, tauM[h]); evHi = max(evHi, tauM[h]); }
+            if (s1_end && !P[h].miss && lc0[h] >= 0 && lc0[h] - (C - 1) < P[h].rows) { evLo = min(evLo, max(0, lc0[h] - (C - 1))); evHi = max(evHi, lc0[h]); }
+        }
+    }
+    const unsigned evSpan = evHi >= evLo ? (unsigned)(evHi - evLo) : 0u;
+    if (evHi < evLo) evLo = 0x7FFFFFFF;
+    uint2 tabN = q_shared ? make_uint2(tab2[qsA[0]].x, tab2[6 * qsB[0]].y) : tab2[qs[0]];
+    int qbN = q_shared ? qsA[1] + 6 * qsB[1] : qs[1];
     int rsN = rs[C];
 
     for (int u0 = 0; u0 < nsteps; u0 += U) {
@@ -309,7 +342,7 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
             //      that enters at the lane's last cell ----
             const uint2 tab = tabN;
             tabN = tab2[qbN];
-            qbN = qs[u + 2];
+            if (q_shared) qbN = qsA[u + 2] + 6 * qsB[u + 2]; else qbN = qs[u + 2];
             S[C + rho] = sel_of(rsN);                // belongs to row u + 1's last cell
             rsN = rs[u + C + 1];
             __builtin_amdgcn_sched_barrier(0);
@@ -344,7 +377,17 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
                 Hx[c] = X;
             };
             // ---- left half: E arrives from lane g - 1 (its right half of the same row, one slot ago) ----
-            if (active) {
+            if (EPG < 0) {
+                static_assert(EPG >= 0 || -EPG <= CL, "a guarded block lies inside the left half");
+                if (active && g != gLo) {
+#pragma unroll
+                    for (int c = 0; c < -EPG && c < CL; ++c) cell(c, Fn[c + 1]);
+                }
+                if (active) {
+#pragma unroll
+                    for (int c = (EPG < 0 ? -EPG : 0); c < CL; ++c) cell(c, Fn[c + 1]);
+                }
+            } else if (active) {
 #pragma unroll
                 for (int c = 0; c < CL; ++c) {
                     if (c < EPG) { if (c >= cLo) cell(c, Fn[c + 1]); }
@@ -363,39 +406,59 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
                 Eout = E;
                 Fedge = LOW2;
                 if (SW) {
-                    // ---- local: the lane's best, exact in column-major order (smallest column, then smallest row) ----
+                    // ---- local: the lane's best, exact in column-major order (smallest column, then smallest row).
+                    //      A row that strictly exceeds the lane's best saves the row index and the strip (v_bfi under a per-half mask;
+                    //      related pairs improve in almost every row, so this is the common path); a row that only EQUALS it can still
+                    //      win by an earlier column (j = tau + c: an earlier cell index by more than the rows in between): rare, exact ----
                     int rm = Hx[0];
 #pragma unroll
                     for (int c = 1; c + 1 < C; c += 2) rm = s_max3(rm, Hx[c], Hx[c + 1]);
                     if ((C & 1) == 0) rm = s_max2(rm, Hx[C - 1]);
-                    const int df = SI32(SPK(rm) - SPK(best));                       // >= 0 per half where the row reaches the best
-                    const int ge = ~df & (int)0x80008000;
-                    if (__builtin_amdgcn_ballot_w64(ge != 0) != 0) {
+                    const s_v2s fifteen = {15, 15};
+                    const int d2 = SI32(SPK(best) - SPK(rm));
+                    const int mgt = SI32(SPK(d2) >> fifteen);                        // 0xFFFF per half where the row exceeds the best
+                    // a half with d2 == 0 whose best is one this lane has SEEN (a bound taken over from the group cannot be tied: it lies
+                    // below the group's best)
+                    const int tie = (d2 - 0x00010001) & ~d2 & (int)0x80008000 & ~fake;
+                    if (__builtin_amdgcn_ballot_w64(tie != 0) != 0) {
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const int r16 = h ? (int)((unsigned)rm >> 16) : (rm & 0xFFFF);
-                            const int b16 = h ? (int)((unsigned)best >> 16) : (best & 0xFFFF);
-                            if (r16 >= b16) {
-                                int cf = C - 1;
+                            if (r16 != (h ? (int)((unsigned)best >> 16) : (best & 0xFFFF)) || (h ? (fake >> 16) : (fake & 0xFFFF))) continue;   // (the packed test may flag a half next to a zero one)
+                            const int srow = h ? (int)((unsigned)bestrow >> 16) : (bestrow & 0xFFFF);
+                            const int sbest = r16 - A_ * ext * (tau - srow);         // the best in the form of the row that saved it
+                            int c2 = C, c1 = C;
 #pragma unroll
-                                for (int c = C - 1; c >= 0; --c) {
-                                    const int x16 = h ? (int)((unsigned)Hx[c] >> 16) : (Hx[c] & 0xFFFF);
-                                    if (x16 == r16) cf = c;
-                                }
-                                const int jj = P[h].i_s + tau + P[h].j0 + g * C + cf - eL;
-                                const int tv = r16 + Cg - k.bias - A_ * ext * tau;
-                                if (tv > bestT[h] || (tv == bestT[h] && jj < bestJ[h])) { bestT[h] = tv; bestJ[h] = jj; bestI[h] = P[h].i_s + tau; }
+                            for (int c = C - 1; c >= 0; --c) {
+                                const int x16 = h ? (int)((unsigned)Hx[c] >> 16) : (Hx[c] & 0xFFFF);
+                                const int v16 = h ? (int)((unsigned)Hsave[c] >> 16) : (Hsave[c] & 0xFFFF);
+                                if (x16 == r16) c2 = c;
+                                if (v16 == sbest) c1 = c;
+                            }
+                            if (tau + c2 < srow + c1) {
+                                const int m = h ? (int)0xFFFF0000 : 0x0000FFFF;
+                                bestrow = (bestrow & ~m) | (((tau & 0xFFFF) * 0x00010001) & m);
+#pragma unroll
+                                for (int c = 0; c < C; ++c) Hsave[c] = (Hsave[c] & ~m) | (Hx[c] & m);
                             }
                         }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(mgt != 0) != 0) {
+                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bestrow) : "v"(mgt), "v"((tau & 0xFFFF) * 0x00010001), "v"(bestrow));
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            int hs;
+                            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hs) : "v"(mgt), "v"(Hx[c]), "v"(Hsave[c]));
+                            Hsave[c] = hs;
+                        }
                         best = s_max2(best, rm);
+                        fake &= ~mgt;
                     }
                     best += a2;
                     Zpe += a2;
                 } else {
                     // ---- global / semi-global: the corner, the last row, the last column ----
-                    const bool evA = tau == tauM[0] || (s1_end && (unsigned)(lc0[0] - tau) < (unsigned)C);
-                    const bool evB = tau == tauM[1] || (s1_end && (unsigned)(lc0[1] - tau) < (unsigned)C);
-                    if (__builtin_amdgcn_ballot_w64(evA || evB) != 0) {
+                    if (__builtin_amdgcn_ballot_w64((unsigned)(tau - evLo) <= evSpan) != 0) {
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const SGeo &p = P[h];
@@ -424,9 +487,47 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
         }
 #pragma unroll
         for (int x = 0; x < C; ++x) S[x] = S[x + U];
+        if (SW && G > 1 && (u0 & 15) == 12) {
+            // Every 16 steps the lanes of a group agree on a lower bound of their pairs' scores -- the largest best any of them holds, in the
+            // form of row 0 -- and each raises its own best to one BELOW it: a lane whose rows stay under the bound can no longer hold the
+            // end cell, so its improvements and ties (the lanes off the alignment's diagonal tie with their small bests in almost every
+            // row) stop costing anything, while a lane that reaches the bound itself still saves.  A best raised this way is not a score the
+            // lane has seen (`fake`); the epilogue gives such halves no candidate.
+            const int rowsRun = max(0, min(u0 + U - g, rowsLane));                   // `best` is in the form of that row
+            const int form = ((A_ * ext * rowsRun) & 0xFFFF) * 0x00010001;
+            int v = laneLive ? best - form : 0;
+#pragma unroll
+            for (int off = G / 2; off >= 1; off >>= 1) v = s_max2(v, __shfl_xor(v, SUBG * off, 64));
+            const int fresh = v - 0x00010001 + form;
+            const int nb = s_max2(best, fresh);
+            const s_v2s fifteen = {15, 15};
+            fake |= SI32((SPK(best) - SPK(nb)) >> fifteen);                          // halves that were raised
+            best = nb;
+        }
     }
 
     // ---- reduction over the group, records ----
+    int bestT[2] = {0, 0}, bestJ[2] = {0x7FFFFFFF, 0x7FFFFFFF}, bestI[2] = {0, 0};     // sw: true score, column, row of the lane's best
+    if (SW) {
+        const int rowsDone = max(0, min(nsteps - g, rowsLane));                     // rows this lane ran: `best` was rebased once per row
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b16 = h ? (int)((unsigned)best >> 16) : (best & 0xFFFF);
+            const int srow = h ? (int)((unsigned)bestrow >> 16) : (bestrow & 0xFFFF);
+            const int sbest = b16 - A_ * ext * (rowsDone - srow);
+            int c1 = C;
+#pragma unroll
+            for (int c = C - 1; c >= 0; --c) {
+                const int v16 = h ? (int)((unsigned)Hsave[c] >> 16) : (Hsave[c] & 0xFFFF);
+                if (v16 == sbest) c1 = c;
+            }
+            if (c1 < C && laneLive && !(h ? (fake >> 16) : (fake & 0xFFFF))) {
+                bestT[h] = sbest + Cg - k.bias - A_ * ext * srow;
+                bestI[h] = P[h].i_s + srow;
+                bestJ[h] = P[h].i_s + srow + P[h].j0 + g * C + c1 - eL;
+            }
+        }
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const SGeo &p = P[h];
@@ -531,7 +632,7 @@ void pmx_banded_retry(int mode, int sg_flags, int open, int ext, const PmxDevMat
                       int band, const int32_t *diag, const unsigned *list, const int *count, pmx_record_t *out, hipStream_t stream);
 
 template <int G, int C, int MODEV>
-static int bs_launch(bool guard_all, long long n, const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
+static int bs_launch(int guard /* 0: one leading cell, 1: every cell, 2: the first 7 cells of <8,13> as one block */, long long n, const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
                      const PmxDevMatrix &m, const SConst &k, const int32_t *diag, const unsigned *perm, int RC, int QC, size_t lds,
                      unsigned *retry_list, int *retry_count, pmx_record_t *out, hipStream_t stream)
 {
@@ -541,7 +642,8 @@ static int bs_launch(bool guard_all, long long n, const uint8_t *qbuf, const int
         if (lds > 48 * 1024) { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_bstrip_kernel<G, C, MODEV, EPG>), 150 * 1024); if (rc) return rc; } \
         hipLaunchKernelGGL((pmx_bstrip_kernel<G, C, MODEV, EPG>), dim3(blocks), dim3(64), lds, stream, qbuf, qoff, q_shared, rbuf, roff, n, \
                            m.scores, m.mapper, m.msize, k, diag, perm, RC, QC, retry_list, retry_count, out); } while (0)
-    if (guard_all) BS_GO(C); else BS_GO(1);
+    if (guard == 2) { if constexpr (G == 8 && C == 13) BS_GO(-7); else return 1; }
+    else if (guard == 1) BS_GO(C); else BS_GO(1);
 #undef BS_GO
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
@@ -568,12 +670,15 @@ int pmx_launch_bstrip(int mode, int sg_flags, int open, int ext, const PmxDevMat
         modev = 0;
     }
     const int U = 4;
-    const int QC = (rows + 2 * G + U + 8 + 3) & ~3, RC = (rows + G + U + cap + 8 + 3) & ~3;
+    // (one shared query: a pair whose band enters the matrix at row i_s reads letters up to i_s + the wave's step count)
+    const int QC = ((q_shared ? 2 * max_qlen : rows) + 2 * G + U + 8 + 3) & ~3, RC = (rows + G + U + cap + 8 + 3) & ~3;
     const int NG = 64 / G;
-    const size_t lds = (size_t)NG * ((size_t)RC + QC);
+    const size_t lds = (size_t)NG * RC + (q_shared ? (size_t)QC : (size_t)NG * QC);
     if (lds > 148 * 1024) return 1;
     const int eL = cap - (2 * band + 1);
-    const bool guard_all = (eL % C) > 1;
+    // offsets in front of the band in the first live lane: one (the common case: capacity = band width + 1) has a guard of its own; <8,13>
+    // with band 48 (7 cells = its whole left half: config 5's second pass) skips them as one block; anything else guards every cell
+    const int guard_all = (eL % C) <= 1 ? 0 : (G == 8 && C == 13 && eL == 7 && !pmx_env("PMX_BSTRIP_CELL_GUARDS")) ? 2 : 1;
     hipError_t e = hipMemsetAsync(retry_count, 0, sizeof(int), stream);
     if (e != hipSuccess) return -(int)e;
     const unsigned *perm = nullptr;

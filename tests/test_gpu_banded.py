@@ -32,14 +32,17 @@ def test_banded_nw_narrow_bands_match_the_banded_oracle(pkg, orc, k):
         assert (want[:, 0] == full[:, 0]).all()
 
 
-@pytest.mark.parametrize("staged", [True, False])
+@pytest.mark.parametrize("form", ["strip", "staged", "percell"])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("k", [1, 3, 15, 16, 31, 32, 63, 100])
-def test_banded_batch_every_mode_with_band_centres(pkg, orc, mode, k, staged, monkeypatch):
-    """both forms of the band-only kernel (sequences staged in LDS + lean interior loop; per-cell form) and, for k > 63, the
-    masked general kernel"""
-    if not staged:
+def test_banded_batch_every_mode_with_band_centres(pkg, orc, mode, k, form, monkeypatch):
+    """the band-strip kernel (band coordinates, C offsets per lane), both forms of the anti-diagonal band-only kernel (sequences
+    staged in LDS + lean interior loop; per-cell form) and, for k > 63, the masked general kernel"""
+    staged = form != "percell"
+    if form == "percell":
         monkeypatch.setenv("PMX_BANDED_NO_STAGING", "1")
+    if form == "staged":
+        monkeypatch.setenv("PMX_BANDED_NO_STRIP", "1")
     rng = np.random.default_rng(8200 + 10 * k + mode)
     pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
     n = 300
@@ -58,7 +61,9 @@ def test_banded_batch_every_mode_with_band_centres(pkg, orc, mode, k, staged, mo
     for dg in (None, diag):
         got = al.align_batch_banded(qs, rs, k, dg)
         kernel = pkg.lib.pmx_last_kernel().decode()
-        assert kernel == ("pmx_general_kernel/banded" if k > 63 else ("pmx_banded_packed_kernel/matrix rows" if mode == 2 else "pmx_banded_staged_kernel") if staged
+        assert kernel == ("pmx_general_kernel/banded" if k > 63
+                          else ("pmx_bstrip_kernel/local" if mode == 2 else "pmx_bstrip_kernel/double skew") if form == "strip"
+                          else ("pmx_banded_packed_kernel/matrix rows" if mode == 2 else "pmx_banded_staged_kernel") if staged
                           else "pmx_banded_kernel"), kernel
         want = orc.align_banded_batch(mode, qb, qo, rb, ro, 5, 2, om, k, dg)
         bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
@@ -93,7 +98,7 @@ def test_cfg5_banded_sw_second_pass(pkg, orc):
     rs = [rbuf[roff[k]:roff[k + 1]].tobytes() for k in range(n)]
     band = 48
     got = al.align_batch_banded([], rs, band, diag)
-    assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_banded_packed_kernel")
+    assert pkg.lib.pmx_last_kernel().decode() == "pmx_bstrip_kernel/local"
     assert (got["score"] <= full["score"]).all()
     assert (got["score"][planted] == full["score"][planted]).all()
     assert (got["end_query"][planted] == full["end_query"][planted]).all() and (got["end_ref"][planted] == full["end_ref"][planted]).all()
@@ -320,9 +325,13 @@ def test_banded_local_packed_kernel_edges_and_low_complexity(pkg, orc, k, monkey
     qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
     want = orc.align_banded_batch(orc.SW, qb, qo, rb, ro, 5, 2, om, k, dg)
     got = al.align_batch_banded(qs, rs, k, dg)
-    assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_banded_packed_kernel")
+    assert pkg.lib.pmx_last_kernel().decode() == "pmx_bstrip_kernel/local"
     bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]))[0]
     assert len(bad) == 0, (k, bad[:6], got[bad[:4]], want[bad[:4]], [(len(qs[x]), len(rs[x]), int(dg[x])) for x in bad[:4]])
+    monkeypatch.setenv("PMX_BANDED_NO_STRIP", "1")
+    ref = al.align_batch_banded(qs, rs, k, dg)
+    assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_banded_packed_kernel")
+    assert (ref == got).all()
     monkeypatch.setenv("PMX_BANDED_NO_PACKED", "1")
     ref = al.align_batch_banded(qs, rs, k, dg)
     assert pkg.lib.pmx_last_kernel().decode() == "pmx_banded_staged_kernel"
@@ -364,7 +373,7 @@ def test_banded_local_shared_query_rows(pkg, orc, k, seed, monkeypatch):
         prof = pkg.Profile.new(q, False, pm)
         al = pkg.Aligner.new().local().profile(prof).matrix(pm).gap_open(5).gap_extend(2).build()
         got = al.align_batch_banded([], rs, k, dg)
-        assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_banded_packed_kernel")
+        assert pkg.lib.pmx_last_kernel().decode() == "pmx_bstrip_kernel/local"
         rb, ro = orc.pack(rs)
         idx = np.arange(n) if n < 1000 else np.unique(np.concatenate([np.arange(0, n, 9), np.arange(140)]))
         rb2, ro2 = orc.pack([rs[t] for t in idx])
@@ -372,6 +381,10 @@ def test_banded_local_shared_query_rows(pkg, orc, k, seed, monkeypatch):
         bad = np.nonzero((got["score"][idx] != want[:, 0]) | (got["end_query"][idx] != want[:, 1]) | (got["end_ref"][idx] != want[:, 2]))[0]
         assert len(bad) == 0, (k, n, idx[bad[:6]], got[idx[bad[:4]]], want[bad[:4]], [(len(rs[idx[x]]), int(dg[idx[x]])) for x in bad[:4]])
         with monkeypatch.context() as mp:
+            mp.setenv("PMX_BANDED_NO_STRIP", "1")
+            ref = al.align_batch_banded([], rs, k, dg)
+            assert pkg.lib.pmx_last_kernel().decode() == "pmx_banded_packed_kernel/shared query rows"
+            assert (ref == got).all()
             mp.setenv("PMX_BANDED_NO_SHARED_ROWS", "1")
             ref = al.align_batch_banded([], rs, k, dg)
             assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_banded_packed_kernel")
