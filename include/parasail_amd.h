@@ -374,6 +374,16 @@ const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen, int32_t ma
 const char *pmx_last_kernel(void);
 /* Every environment switch the library reads, one "NAME\tkind\twhat\n" line each (parasail-rs_amd/csrc/pmx_switches.h). */
 const char *pmx_switches(void);
+/* The 66 matrix names the reference documents (src/matrix/mod.rs:46-50), one per line, into buf (NUL-terminated, truncated to cap);
+ * returns the bytes needed.  parasail_matrix_lookup() embeds blosum62 / nuc44 and resolves the others from files (pmx_last_error()
+ * tells a documented name whose file is missing from an unknown name, and why a file was refused). */
+int pmx_documented_matrix_names(char *buf, int cap);
+/* Test hooks of the band-strip kernel (parasail-rs_amd/csrc/pmx_bstrip.hip; model: tests/bstrip_model.py): the host's window
+ * predicate -- 1 and the bias / low constants of the stored form when the int16 window holds a launch of that shape, else 0 -- and
+ * the lane shape (lanes per pair, offsets per lane) chosen for a band. */
+int pmx_bstrip_window(int mode, int max_qlen, int max_rlen, int open, int extend, int score_min, int score_max, int capacity, int rows,
+                      int double_skew, int *bias, int *low);
+int pmx_bstrip_shape(int band, int *lanes_per_pair, int *offsets_per_lane);
 
 #ifdef __cplusplus
 }

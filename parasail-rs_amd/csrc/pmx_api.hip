@@ -167,18 +167,85 @@ static void init_builtins()
 }
 
 extern "C" parasail_matrix_t *parasail_matrix_from_file(const char *filename);
+extern "C" void parasail_matrix_free(parasail_matrix_t *matrix);
 
-// The reference documents 66 built-in names (blosum30..100, pam10..500: src/matrix/mod.rs:46-50); the tables themselves live in
+// The reference documents 66 built-in names (blosum{30..100}, pam{10..500}: src/matrix/mod.rs:46-50); the tables themselves live in
 // the parasail C library, which is not in this image, and typing 64 of them from memory cannot be checked here.  Embedded:
 // blosum62, nuc44 (both verified against files: tests/golden/blosum62.txt, the reference's own tests/square.txt).  Every other
-// name resolves from $PMX_MATRIX_DIR/<name> or <name>.txt (NCBI format, the loader of parasail_matrix_from_file) and then
+// name resolves from $PMX_MATRIX_DIR/<name>[.txt|.mat] (NCBI format, the loader of parasail_matrix_from_file) and then
 // behaves like a built-in: cached for the life of the process, never freed, set_value rejected.
+//
+// ONE table of the documented names with what their files must look like: the 20 residues + B Z X * of the NCBI files
+// (24 symbols; a file with further columns, e.g. J / U / O of newer NCBI releases, is accepted as long as these are there).
+static const char *const pmx_documented_residues = "ARNDCQEGHILKMFPSTWYV";
+static bool documented_matrix_name(const std::string &lname, std::string *family)
+{
+    static const int blosum[] = {30, 35, 40, 45, 50, 55, 60, 62, 65, 70, 75, 80, 85, 90, 95, 100};
+    auto number = [&](const char *prefix, int *out) {
+        const size_t pl = strlen(prefix);
+        if (lname.compare(0, pl, prefix) != 0 || lname.size() == pl || lname.size() > pl + 3) return false;
+        int v = 0;
+        for (size_t i = pl; i < lname.size(); ++i) { if (!isdigit((unsigned char)lname[i])) return false; v = 10 * v + (lname[i] - '0'); }
+        if (lname[pl] == '0') return false;
+        *out = v; return true;
+    };
+    int v = 0;
+    if (number("blosum", &v)) { for (int b : blosum) if (b == v) { if (family) *family = "blosum"; return true; } return false; }
+    if (number("pam", &v)) { if (v >= 10 && v <= 500 && v % 10 == 0) { if (family) *family = "pam"; return true; } return false; }
+    return false;
+}
+// the 66 names, for tests and for `pmx_last_error()` ("known name, file missing" vs "unknown name")
+extern "C" int pmx_documented_matrix_names(char *buf, int cap)
+{
+    std::string all;
+    static const int blosum[] = {30, 35, 40, 45, 50, 55, 60, 62, 65, 70, 75, 80, 85, 90, 95, 100};
+    for (int b : blosum) all += "blosum" + std::to_string(b) + "\n";
+    for (int p = 10; p <= 500; p += 10) all += "pam" + std::to_string(p) + "\n";
+    if (buf && cap > 0) { strncpy(buf, all.c_str(), (size_t)cap - 1); buf[cap - 1] = 0; }
+    return (int)all.size() + 1;
+}
+
+// Load-time self-check of a file that claims a documented name: a damaged or mislabelled table is refused (a silently wrong table
+// is worse than a failed lookup).  Square; the 20 residues, B, Z, X and * present; symmetric; positive diagonal on the residues;
+// every `*` score against a letter is the table's minimum; B lies between N and D, Z between Q and E, X inside the residues' range.
+static bool documented_matrix_selfcheck(const parasail_matrix_t *m, std::string *why)
+{
+    if (m->type != PARASAIL_MATRIX_TYPE_SQUARE) { *why = "not a square matrix"; return false; }
+    const int n = m->size;
+    auto idx = [&](char c) -> int { const char *p = m->alphabet ? strchr(m->alphabet, c) : nullptr; return p ? (int)(p - m->alphabet) : -1; };
+    auto at = [&](int a, int b) { return m->matrix[(size_t)a * n + b]; };
+    int res[20];
+    for (int r = 0; r < 20; ++r) { res[r] = idx(pmx_documented_residues[r]); if (res[r] < 0) { *why = std::string("residue ") + pmx_documented_residues[r] + " missing"; return false; } }
+    const int iB = idx('B'), iZ = idx('Z'), iX = idx('X'), iS = idx('*');
+    if (iB < 0 || iZ < 0 || iX < 0 || iS < 0) { *why = "one of B Z X * missing"; return false; }
+    for (int a = 0; a < n; ++a) for (int b = 0; b < a; ++b) if (at(a, b) != at(b, a)) {
+        *why = std::string("not symmetric at ") + m->alphabet[a] + "/" + m->alphabet[b]; return false; }
+    for (int r = 0; r < 20; ++r) if (at(res[r], res[r]) <= 0) { *why = std::string("diagonal of ") + pmx_documented_residues[r] + " is not positive"; return false; }
+    for (int a = 0; a < n; ++a) if (a != iS && at(iS, a) != m->min) { *why = std::string("* against ") + m->alphabet[a] + " is not the table's minimum"; return false; }
+    auto between = [&](int amb, char c1, char c2, const char *nm) {
+        const int i1 = idx(c1), i2 = idx(c2);
+        for (int r = 0; r < 20; ++r) {
+            const int lo = std::min(at(i1, res[r]), at(i2, res[r])), hi = std::max(at(i1, res[r]), at(i2, res[r]));
+            if (at(amb, res[r]) < lo || at(amb, res[r]) > hi) { *why = std::string(nm) + " against " + pmx_documented_residues[r] + " is outside the range of the residues it stands for"; return false; }
+        }
+        return true;
+    };
+    if (!between(iB, 'N', 'D', "B") || !between(iZ, 'Q', 'E', "Z")) return false;
+    for (int r = 0; r < 20; ++r) {
+        int lo = INT32_MAX, hi = INT32_MIN;
+        for (int q = 0; q < 20; ++q) { lo = std::min(lo, at(res[q], res[r])); hi = std::max(hi, at(res[q], res[r])); }
+        if (at(iX, res[r]) < lo || at(iX, res[r]) > hi) { *why = std::string("X against ") + pmx_documented_residues[r] + " is outside the residues' range"; return false; }
+    }
+    return true;
+}
+
 static const parasail_matrix_t *lookup_in_matrix_dir(const std::string &lname)
 {
     static std::mutex mx;
     static std::unordered_map<std::string, const parasail_matrix_t *> cache;
-    for (char c : lname) if (!(isalnum((unsigned char)c) || c == '_' || c == '-' || c == '.')) return nullptr;    // a name, not a path
-    if (lname.empty() || lname[0] == '.') return nullptr;
+    for (char c : lname) if (!(isalnum((unsigned char)c) || c == '_' || c == '-' || c == '.')) { set_err("matrix lookup: '%s' is not a name", lname.c_str()); return nullptr; }
+    if (lname.empty() || lname[0] == '.') { set_err("matrix lookup: empty name"); return nullptr; }
+    const bool documented = documented_matrix_name(lname, nullptr);
     std::lock_guard<std::mutex> lk(mx);
     // $PMX_MATRIX_DIR, else the directory shipped beside the library: <libdir>/../matrices (parasail-rs_amd/matrices in this tree)
     std::string dir;
@@ -192,8 +259,8 @@ static const parasail_matrix_t *lookup_in_matrix_dir(const std::string &lname)
             dir = (slash == std::string::npos ? std::string(".") : so.substr(0, slash)) + "/../matrices";
         }
     }
-    if (dir.empty()) return nullptr;
-    const std::string key = dir + "\n" + lname;               // hits AND misses are remembered per directory (a miss costs three fopen calls)
+    if (dir.empty()) { set_err("matrix lookup: no matrix directory"); return nullptr; }
+    const std::string key = dir + "\n" + lname;               // hits are remembered per directory; a miss is looked up again (a file may have arrived)
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     parasail_matrix_t *m = nullptr;
@@ -202,7 +269,20 @@ static const parasail_matrix_t *lookup_in_matrix_dir(const std::string &lname)
         m = parasail_matrix_from_file(path.c_str());
         if (m) break;
     }
-    if (!m) { cache[key] = nullptr; return nullptr; }
+    if (!m) {
+        if (documented) set_err("matrix lookup: '%s' is a documented name (src/matrix/mod.rs:46-50) whose table is not embedded, and no file %s/%s[.txt|.mat] "
+                                "was found: put the NCBI file there (or set PMX_MATRIX_DIR)", lname.c_str(), dir.c_str(), lname.c_str());
+        else set_err("matrix lookup: unknown matrix name '%s' (not embedded, not documented, no file in %s)", lname.c_str(), dir.c_str());
+        return nullptr;
+    }
+    if (documented) {
+        std::string why;
+        if (!documented_matrix_selfcheck(m, &why)) {
+            set_err("matrix lookup: the file found for '%s' in %s is refused: %s", lname.c_str(), dir.c_str(), why.c_str());
+            parasail_matrix_free(m);
+            return nullptr;
+        }
+    }
     MatrixBox *b = nullptr;
     {   // from here on it is a built-in: out of the table of caller-owned matrices, not writable
         std::lock_guard<std::mutex> lk2(g_mx_mutex);
@@ -1378,15 +1458,28 @@ static int long_batch(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch 
     if (chunk > n) chunk = n;
     void *scr = nullptr;
     if (scratch_reserve((size_t)chunk * per_pair, &scr, SCR_LONG)) return 1;
+    // the bands of a pair wait for one another across workgroups; the wait is bounded (pmx_long.hip): ~2 us a poll
+    int spin_limit = 1 << 20;
+    if (const char *e = pmx_env("PMX_LONG_SPIN_LIMIT")) spin_limit = atoi(e);             // tests force the give-up path
+    HIP_OR_RET(hipMemsetAsync(scr, 0, 64, st));
     for (int64_t c0 = 0; c0 < n; c0 += chunk) {
         PmxBatch b = b0;
         b.perm = nullptr;                                  // (a processing order is a hint: records are indexed by pair)
         b.n = (n - c0 < chunk) ? n - c0 : chunk;
         if (!b.q_shared) b.qoff = b0.qoff + c0;
         b.roff = b0.roff + c0;
-        const int rc = pmx_launch_long(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, R, scr, d_out + c0, sat_above, force_sat, st);
+        const int rc = pmx_launch_long(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, R, scr, d_out + c0, sat_above, force_sat, st, spin_limit);
         if (rc < 0) { set_err("long-pair kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
         if (rc) return c0 == 0 ? 1 : (set_err("long-pair kernel refused a later chunk"), -1);
+    }
+    // did a band give up waiting?  (The one host synchronisation of this path; one-pair calls synchronise right after anyway.)
+    int gave_up = 0;
+    HIP_OR_RET(hipMemcpyAsync(&gave_up, scr, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_OR_RET(hipStreamSynchronize(st));
+    if (gave_up) {
+        set_err("long-pair kernel: a band's bounded wait for the band above ran out (dispatch order assumption broken, or PMX_LONG_SPIN_LIMIT); "
+                "the call was redone on the per-pair kernels");
+        return 1;
     }
     g_last_kernel = R == 4 ? "pmx_long32_kernel<4>/bands across the chip" : "pmx_long32_kernel<16>/bands across the chip";
     return 0;

@@ -331,7 +331,7 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
     const unsigned evSpan = evHi >= evLo ? (unsigned)(evHi - evLo) : 0u;
     if (evHi < evLo) evLo = 0x7FFFFFFF;
     uint2 tabN = q_shared ? make_uint2(tab2[qsA[0]].x, tab2[6 * qsB[0]].y) : tab2[qs[0]];
-    int qbN = q_shared ? qsA[1] + 6 * qsB[1] : qs[1];
+    int qbN = q_shared ? (int)qsA[1] : (int)qs[1], qbN2 = q_shared ? (int)qsB[1] : 0;      // (one shared query: the two letters, combined when their tables are read)
     int rsN = rs[C];
 
     for (int u0 = 0; u0 < nsteps; u0 += U) {
@@ -341,8 +341,8 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
             // ---- loads of the next row: its tables (the letter byte was read a row ago), the letter byte after that, the selector
             //      that enters at the lane's last cell ----
             const uint2 tab = tabN;
-            tabN = tab2[qbN];
-            if (q_shared) qbN = qsA[u + 2] + 6 * qsB[u + 2]; else qbN = qs[u + 2];
+            tabN = tab2[qbN + 6 * qbN2];
+            if (q_shared) { qbN = qsA[u + 2]; qbN2 = qsB[u + 2]; } else qbN = qs[u + 2];
             S[C + rho] = sel_of(rsN);                // belongs to row u + 1's last cell
             rsN = rs[u + C + 1];
             __builtin_amdgcn_sched_barrier(0);
@@ -419,7 +419,9 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
                     const int mgt = SI32(SPK(d2) >> fifteen);                        // 0xFFFF per half where the row exceeds the best
                     // a half with d2 == 0 whose best is one this lane has SEEN (a bound taken over from the group cannot be tied: it lies
                     // below the group's best)
-                    const int tie = (d2 - 0x00010001) & ~d2 & (int)0x80008000 & ~fake;
+                    // ... and only while the saved cell is young: a later row wins a tie by an earlier COLUMN (tau + c), i.e. within C - 2 rows
+                    const int age = (tau & 0xFFFF) * 0x00010001 - bestrow;
+                    const int tie = (d2 - 0x00010001) & ~d2 & (int)0x80008000 & ~fake & (age - (C - 1) * 0x00010001);
                     if (__builtin_amdgcn_ballot_w64(tie != 0) != 0) {
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
@@ -466,19 +468,23 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
                             if (p.miss || tau >= p.rows) continue;
                             const int lc = lc0[h] - tau;
                             const bool lastrow = tau == tauM[h];
-                            const bool incol = s1_end && (unsigned)lc < (unsigned)C;
-                            if (!lastrow && !incol) continue;
+                            const bool incol = s1_end && (unsigned)lc < (unsigned)C && g * C + lc - eL >= 0;
+                            if (incol) {                                             // the cell of column rl - 1: one select per cell
+                                int x16 = 0;
+#pragma unroll
+                                for (int c = 0; c < C; ++c) x16 = c == lc ? (h ? (int)((unsigned)Hx[c] >> 16) : (Hx[c] & 0xFFFF)) : x16;
+                                const int tv = x16 + Cg - k.bias - (A_ * tau + B_ * (g * C + lc - eL)) * ext;
+                                if (tv > bcolH[h]) { bcolH[h] = tv; bcolI[h] = i; }
+                            }
+                            if (!lastrow) continue;
 #pragma unroll
                             for (int c = 0; c < C; ++c) {
                                 const int d = g * C + c - eL, j = i + p.j0 + d;
                                 if (d < 0 || j < 0 || j >= p.rl) continue;
                                 const int x16 = h ? (int)((unsigned)Hx[c] >> 16) : (Hx[c] & 0xFFFF);
                                 const int tv = x16 + Cg - k.bias - (A_ * tau + B_ * d) * ext;
-                                if (lastrow) {
-                                    if (j == p.rl - 1) corner[h] = tv;
-                                    if (s2_end && tv > browH[h]) { browH[h] = tv; browJ[h] = j; }
-                                }
-                                if (incol && c == lc && tv > bcolH[h]) { bcolH[h] = tv; bcolI[h] = i; }
+                                if (j == p.rl - 1) corner[h] = tv;
+                                if (s2_end && tv > browH[h]) { browH[h] = tv; browJ[h] = j; }
                             }
                         }
                     }

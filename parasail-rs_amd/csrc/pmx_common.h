@@ -203,8 +203,10 @@ int pmx_launch_cigar_render_slots(const uint32_t *ops, const int64_t *qoff, cons
 // One long pair (or a few) across the chip: bands of the query on different CUs, pipelined through HBM granules (pmx_long.hip).
 // R = rows per lane (4 or 16).  0 launched, 1 not eligible, <0 HIP error; `scratch` holds pmx_long_scratch_bytes() bytes.
 size_t pmx_long_scratch_bytes(long long n, int max_qlen, int max_rlen, int R, long long *bstride, int *nbmax);
+// The first 64 bytes of `scratch` are the call's abort word: the caller zeroes them before the first launch and reads them after the
+// last (non-zero: a band's bounded wait ran out -- every record of the call is marked PMX_FLAG_RERUN and has to be redone elsewhere).
 int pmx_launch_long(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int R,
-                    void *scratch, pmx_record_t *d_out, int sat_above, int force_sat, hipStream_t stream);
+                    void *scratch, pmx_record_t *d_out, int sat_above, int force_sat, hipStream_t stream, int spin_limit = 1 << 20);
 
 // Run-time CIGAR letter convention (switch PMX_CIGAR_SWAP_ID, read per call): 1 = exchange I and D in everything handed out.
 int pmx_cigar_swapped();

@@ -13,7 +13,13 @@
 // wave_shr, which lane 0 keeps.  A granule is data and tag at once (MI355X_MICROARCH.md, hand-off by data-tagged granules: a
 // single aligned 8-byte sc1 store is observed whole), so there is no flag, no fence and no barrier anywhere.  The bands form a
 // software pipeline across the chip: band b + 1 runs ~130 steps behind band b.  A consumer only ever waits for a producer
-// with a LOWER workgroup index, which is dispatched no later than itself: the grid drains for any size.
+// with a LOWER workgroup index.  Forward progress rests on ONE assumption about the hardware that HIP does not promise: the
+// workgroups of a grid are dispatched in index order (per XCD), so the lowest unfinished band of every grid is resident and
+// depends on finished bands only -- also when two such grids share the chip (two host threads, each with its own scratch and
+// stream: tests/test_gpu_long.py runs that).  The wait is therefore BOUNDED: a band that polls `spin_limit` times (seconds; a
+// legitimate wait is the producer's next 64 columns, microseconds), or sees the launch's abort word set, sets the word and
+// leaves; every band downstream finds the word (or runs into the limit itself) and leaves too, the finalize kernel marks the
+// launch's records, and the host (`long_batch`) redoes the call on the per-pair kernels and says so in pmx_last_error().
 // Reference symbols take the same road: 64 mapped symbols per lane-parallel load, rotated to lane 0 and handed down the lanes
 // with the wave -- no reference in LDS, no length limit.  The LDS holds the band's query profile only (int16 [symbol][row]).
 //
@@ -37,6 +43,8 @@ struct PmxLongArgs {
     unsigned long long *bound; long long bstride;      // granules per (pair, band) boundary
     int *cand;                                         // 8 ints per (pair, band)
     pmx_record_t *out; int sat_above; int force_sat;
+    int *abort_word;                                   // device word, zero before the launch: a band gave up waiting
+    int spin_limit;                                    // polls of one wait before a band gives up
 };
 
 __device__ __forceinline__ int dpp_wave_shr(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, 0x138 /*wave_shr:1*/, 0xF, 0xF, false); }
@@ -99,6 +107,7 @@ void pmx_long32_kernel(PmxLongArgs a)
     // chunks of 64 columns: mapped reference symbols (as profile row offsets) and, below band 0, the boundary granules
     int symch = 0, Hb = 0, Fb = 0, symcur = msize * (BR * 2);
     int nraw = 0; unsigned long long ngran = 0;
+    bool dead = false;                                 // wave-uniform: this band gave up waiting (or found the abort word)
     auto prefetch_sym = [&](int base) { const int c = base + lane; nraw = c < rl ? (int)r[c] : -1; };
     auto prefetch_bound = [&](int base) { if (bin) ngran = __hip_atomic_load(bin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     // symbols of columns [base, base + 64) take over the rotating register (one step BEFORE the first of them is worked on:
@@ -109,7 +118,14 @@ void pmx_long32_kernel(PmxLongArgs a)
     };
     auto reload_bound = [&](int base) {
         if (bin && base < RU) {                            // (the chunk behind the reference is padding on both sides: never written, never needed)
+            int spins = 0;
             while (__builtin_amdgcn_ballot_w64(ngran == LONG_SENT) != 0) {          // the producer is not that far yet
+                if (spins >= a.spin_limit || ((spins & 63) == 63 && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    if (lane == 0) __hip_atomic_store(a.abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dead = true;
+                    return;
+                }
+                ++spins;
                 __builtin_amdgcn_s_sleep(8);
                 ngran = __hip_atomic_load(bin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -195,6 +211,7 @@ void pmx_long32_kernel(PmxLongArgs a)
     advance(w0);
     for (int base = 0; base < T; base += 64) {
         reload_bound(base);
+        if (dead) return;                                  // (nothing downstream is fed any more: those bands leave the same way)
         if (base >= 64 && base < tB) {
             for (int t = base; t < base + 64; t += 2) {
                 step(HA, HB, w0, w1, t, std::false_type());
@@ -256,6 +273,11 @@ __global__ void pmx_long_finalize_kernel(PmxLongArgs a, int mode, int R)
     const int NB = (ql + BR - 1) / BR;
     const int *cand = a.cand + (size_t)pair * a.nbmax * 8;
     pmx_record_t rec; rec.flags = 0;
+    if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {       // a band gave up: nothing of this launch counts
+        rec.score = 0; rec.end_query = 0; rec.end_ref = 0; rec.flags = PMX_FLAG_RERUN;
+        a.out[pair] = rec;
+        return;
+    }
     if (mode == PMX_MODE_SW) {
         int sc = -1, col = 0x7FFFFFFF, row = 0x7FFFFFFF;
         for (int b = 0; b < NB; ++b) {
@@ -288,12 +310,12 @@ size_t pmx_long_scratch_bytes(long long n, int max_qlen, int max_rlen, int R, lo
     const int BR = 64 * R;
     *nbmax = (max_qlen + BR - 1) / BR;
     *bstride = *nbmax > 1 ? (((long long)max_rlen + 63) & ~63LL) + 64 : 0;      // one band per pair: nothing is handed on
-    return (size_t)n * (size_t)*nbmax * ((size_t)*bstride * 8 + 32);
+    return (size_t)n * (size_t)*nbmax * ((size_t)*bstride * 8 + 32) + 64;      // + the abort word (the first 64 bytes of the scratch)
 }
 
 // 0 launched, 1 not eligible, <0 HIP error.  `scratch` = pmx_long_scratch_bytes() bytes.
 int pmx_launch_long(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int R,
-                    void *scratch, pmx_record_t *d_out, int sat_above, int force_sat, hipStream_t stream)
+                    void *scratch, pmx_record_t *d_out, int sat_above, int force_sat, hipStream_t stream, int spin_limit)
 {
     if (b.perm || m.msize > 64) return 1;
     if (m.max + open > 32000 || m.min + open < -16000 || open < 0 || ext < 0) return 1;      // int16 profile entries
@@ -304,12 +326,15 @@ int pmx_launch_long(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_f
     long long bstride = 0; int nbmax = 0;
     const size_t bytes = pmx_long_scratch_bytes(b.n, b.max_qlen, b.max_rlen, R, &bstride, &nbmax);
     a.nbmax = nbmax; a.bstride = bstride;
-    a.bound = reinterpret_cast<unsigned long long *>(scratch);
+    // scratch: [abort word, 64 bytes -- zeroed by the caller before the first launch of a call][boundary granules][candidates]
+    a.abort_word = reinterpret_cast<int *>(scratch);
+    a.spin_limit = spin_limit;
+    a.bound = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(scratch) + 64);
     const size_t bound_bytes = (size_t)b.n * nbmax * (size_t)bstride * 8;
-    a.cand = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scratch) + bound_bytes);
+    a.cand = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scratch) + 64 + bound_bytes);
     a.out = d_out; a.sat_above = sat_above; a.force_sat = force_sat;
     (void)bytes;
-    hipError_t e = bound_bytes ? hipMemsetAsync(scratch, 0x80, bound_bytes, stream) : hipSuccess;
+    hipError_t e = bound_bytes ? hipMemsetAsync(a.bound, 0x80, bound_bytes, stream) : hipSuccess;
     if (e != hipSuccess) return -(int)e;
     const int BR = 64 * R;
     const size_t lds = (size_t)(m.msize + 1) * BR * 2 + (size_t)m.msize * m.msize * 2 + 256 + 16;

@@ -241,30 +241,122 @@ def test_matrix_lookup_resolves_documented_names_from_a_directory(pkg, tmp_path,
             pkg.Matrix.from_name(bad)
 
 
-def test_matrix_lookup_default_directory_and_aliases(pkg, monkeypatch):
-    """Without $PMX_MATRIX_DIR the library looks in <libdir>/../matrices (shipped with the package); misses are remembered per
-    directory; `dnafull` is the NUC.4.4 table under its EMBOSS name."""
+def test_matrix_lookup_default_directory_and_aliases(pkg, tmp_path, monkeypatch):
+    """Without $PMX_MATRIX_DIR the library looks in <libdir>/../matrices (shipped with the package; nothing is written there by
+    this test); `dnafull` is the NUC.4.4 table under its EMBOSS name; a miss is NOT remembered -- a file dropped into the
+    directory after a failed lookup is found by the same process (matrices/README.md promises names resolve with no rebuild)."""
     import shutil
     monkeypatch.delenv("PMX_MATRIX_DIR", raising=False)
     assert (pkg.Matrix.from_name("dnafull").to_numpy() == pkg.Matrix.from_name("nuc44").to_numpy()).all()
-    shipped = os.path.join(ROOT, "parasail-rs_amd", "matrices")
-    assert os.path.isdir(shipped)
-    name = "pmxtestonly77"
+    assert os.path.isdir(os.path.join(ROOT, "parasail-rs_amd", "matrices"))
     with pytest.raises(pkg.FailedLookup):
-        pkg.Matrix.from_name(name)
-    dst = os.path.join(shipped, name + ".txt")
-    try:
-        shutil.copy(os.path.join(ROOT, "tests", "golden", "blosum62.txt"), dst)
-        with pytest.raises(pkg.FailedLookup):                  # the miss above is cached for this directory ...
+        pkg.Matrix.from_name("pmxtestonly77")
+    assert b"unknown matrix name" in pkg.lib.pmx_last_error() and b"parasail-rs_amd" in pkg.lib.pmx_last_error()
+    monkeypatch.setenv("PMX_MATRIX_DIR", str(tmp_path))
+    with pytest.raises(pkg.FailedLookup):
+        pkg.Matrix.from_name("pmxtestonly77")
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "blosum62.txt"), tmp_path / "pmxtestonly77.txt")
+    m = pkg.Matrix.from_name("pmxtestonly77")                 # the miss above was not cached
+    assert (m.to_numpy() == pkg.Matrix.from_name("blosum62").to_numpy()).all()
+
+
+def _write_ncbi(path, alphabet, table):
+    with open(path, "w") as fh:
+        fh.write("# generated by tests/test_abi.py\n   " + "  ".join(alphabet) + "\n")
+        for a, row in zip(alphabet, table):
+            fh.write(a + " " + " ".join("%2d" % v for v in row) + "\n")
+
+
+def test_all_66_documented_matrix_names_through_the_directory(pkg, tmp_path, monkeypatch):
+    """src/matrix/mod.rs:46-50 documents 16 BLOSUM and 50 PAM names.  The library lists them (`pmx_documented_matrix_names`); each
+    one resolves from $PMX_MATRIX_DIR once its NCBI file is there (generated here: structurally valid tables, a different one per
+    name -- the loader and the name table are what is tested, not table values), says "documented name ... no file" while it is
+    not, and a damaged file under a documented name is refused with the reason (load-time self-check: symmetric, positive
+    diagonal, `*` = the minimum, B / Z / X inside the range of the residues they stand for)."""
+    import numpy as np
+    buf = C.create_string_buffer(4096)
+    need = pkg.lib.pmx_documented_matrix_names(buf, 4096)
+    names = buf.value.decode().split()
+    assert need <= 4096 and len(names) == 66 and len(set(names)) == 66
+    assert names[:3] == ["blosum30", "blosum35", "blosum40"] and "blosum62" in names and names[-1] == "pam500" and "pam10" in names
+    monkeypatch.setenv("PMX_MATRIX_DIR", str(tmp_path))
+    b62 = pkg.Matrix.from_name("blosum62").to_numpy().astype(np.int64)
+    alphabet = list("ARNDCQEGHILKMFPSTWYVBZX*")
+    for k, name in enumerate(names):
+        if name == "blosum62":
+            continue
+        with pytest.raises(pkg.FailedLookup):
             pkg.Matrix.from_name(name)
-        other = name + "b"                                    # ... a name not asked for before is found
-        shutil.copy(dst, os.path.join(shipped, other))
-        m = pkg.Matrix.from_name(other)
-        assert (m.to_numpy() == pkg.Matrix.from_name("blosum62").to_numpy()).all()
-    finally:
-        for f in (dst, os.path.join(shipped, name + "b")):
-            if os.path.exists(f):
-                os.remove(f)
+        msg = pkg.lib.pmx_last_error()
+        assert b"documented name" in msg and name.encode() in msg, msg
+        t = b62.copy()
+        t[:23, :23] += (k % 3)                                # another table per name, same structure (symmetric shift of the letters' block)
+        t[23, :23] = t[:23, 23] = t[:23, :23].min() - 1       # `*`: the minimum; */* stays 1
+        _write_ncbi(tmp_path / (name + (".txt" if k % 2 else "")), alphabet, t)
+        m = pkg.Matrix.from_name(name.upper() if k % 5 == 0 else name)
+        assert m.size == 24 and (m.to_numpy() == t).all(), name
+        with pytest.raises(pkg.NotBuiltIn):
+            m.set_value(0, 0, 5)
+    for bad in ("blosum63", "pam15", "pam510", "pam0", "blosum", "pam", "blosum062"):
+        with pytest.raises(pkg.FailedLookup):
+            pkg.Matrix.from_name(bad)
+        assert b"unknown matrix name" in pkg.lib.pmx_last_error(), (bad, pkg.lib.pmx_last_error())
+
+    A = {c: i for i, c in enumerate(alphabet)}
+
+    def asym(t): t[A["W"], A["Y"]] += 1
+    def diag(t): t[A["S"], A["S"]] = 0
+    def star(t): t[A["*"], A["K"]] = t[A["K"], A["*"]] = 0
+    def bout(t): t[A["B"], A["N"]] = t[A["N"], A["B"]] = 9
+    def xout(t): t[A["X"], A["W"]] = t[A["W"], A["X"]] = 12
+    for name, edit, reason in (("blosum45", asym, b"not symmetric"), ("pam250", diag, b"diagonal of S"), ("pam120", star, b"* against K"),
+                               ("blosum80", bout, b"B against N"), ("pam30", xout, b"X against W")):
+        # force a cache miss: these names were loaded above under this directory, so use a second directory
+        d2 = tmp_path / ("second_" + name)
+        d2.mkdir()
+        monkeypatch.setenv("PMX_MATRIX_DIR", str(d2))
+        t = b62.copy(); edit(t)
+        _write_ncbi(d2 / name, alphabet, t)
+        with pytest.raises(pkg.FailedLookup):
+            pkg.Matrix.from_name(name)
+        assert reason in pkg.lib.pmx_last_error(), (name, pkg.lib.pmx_last_error())
+        # an UNdocumented name is the user's own table: loaded as it is
+        _write_ncbi(d2 / "mytable", alphabet, t)
+        assert (pkg.Matrix.from_name("mytable").to_numpy() == t).all()
+        monkeypatch.setenv("PMX_MATRIX_DIR", str(tmp_path))
+
+
+def test_embedded_blosum62_against_the_published_description(pkg):
+    """(round-3 review: csrc/pmx_matrices.h and tests/golden/blosum62.txt were typed by the same hand.)  An independent check written
+    from the literature's description of BLOSUM62 (Henikoff & Henikoff 1992; the NCBI file's layout), not from the table: order
+    ARNDCQEGHILKMFPSTWYVBZX*, symmetric, the diagonal 4 5 6 6 9 5 5 6 8 4 4 5 5 6 7 4 5 11 7 4, extremes -4 / 11 (W/W), the
+    well-known pairs (I/V 3, F/Y 3, K/R 2, D/E 2, L/M 2, I/L 2, W/Y 2, H/Y 2, N/D 1, S/T 1, Q/E 2, C against W -2), B and Z between
+    the residues they stand for, `*` = -4 against every letter and 1 against itself."""
+    import numpy as np
+    m = pkg.Matrix.from_name("blosum62")
+    t = m.to_numpy()
+    al = "ARNDCQEGHILKMFPSTWYVBZX*"
+    assert m.size == 24 and m.inner.contents.alphabet.decode() == al
+    A = {c: i for i, c in enumerate(al)}
+    assert (t == t.T).all()
+    assert [int(t[A[c], A[c]]) for c in al[:20]] == [4, 5, 6, 6, 9, 5, 5, 6, 8, 4, 4, 5, 5, 6, 7, 4, 5, 11, 7, 4]
+    assert t.min() == -4 and t.max() == 11 and t[A["W"], A["W"]] == 11
+    known = (("I", "V", 3), ("F", "Y", 3), ("K", "R", 2), ("D", "E", 2), ("L", "M", 2), ("I", "L", 2), ("W", "Y", 2), ("H", "Y", 2),
+                    ("N", "D", 1), ("S", "T", 1), ("Q", "E", 2), ("C", "W", -2), ("G", "P", -2), ("A", "S", 1), ("A", "G", 0), ("L", "V", 1),
+                    ("M", "V", 1), ("I", "M", 1), ("Q", "K", 1), ("Q", "R", 1), ("E", "K", 1), ("N", "S", 1), ("N", "H", 1), ("W", "F", 1))
+    for a, b, v in known:
+        assert t[A[a], A[b]] == v, (a, b, int(t[A[a], A[b]]))
+    for amb, x, y in (("B", "N", "D"), ("Z", "Q", "E")):
+        for c in al[:20]:
+            lo, hi = sorted((int(t[A[x], A[c]]), int(t[A[y], A[c]])))
+            assert lo <= t[A[amb], A[c]] <= hi, (amb, c)
+    assert (t[A["*"], :23] == -4).all() and t[A["*"], A["*"]] == 1
+    # every residue scores itself higher than any other residue, and the conservative substitutions listed above are ALL the
+    # positive residue pairs of the matrix (21 of the 190)
+    blk = t[:20, :20]
+    assert all(blk[i, i] > np.delete(blk[i], i).max() for i in range(20))
+    positive = {frozenset((al[i], al[j])) for i in range(20) for j in range(i + 1, 20) if blk[i, j] > 0}
+    assert positive == {frozenset((a, b)) for a, b, v in known if v > 0} and len(positive) == 21
 
 
 def test_environment_switches_are_tabled(pkg):

@@ -241,3 +241,66 @@ def test_fuzz_band_kernel_shapes_modes_and_scoring(pkg, orc, seed):
         bad = np.nonzero((got != want).any(axis=1))[0]
         assert len(bad) == 0, (seed, it, mode, eff, open_, ext, match, mismatch, na, bad[:4], got[bad[:4]], want[bad[:4]],
                                [(len(qs[k]), len(rs[k])) for k in bad[:4]])
+
+
+def test_bounded_wait_gives_up_and_the_call_is_redone(pkg, orc, monkeypatch):
+    """(round-3 review) a band's wait for the band above is bounded: with the limit forced to 0 every wait gives up at once, the
+    launch's abort word makes every other band leave, and the call is redone on the per-pair kernels -- same records, the give-up
+    reported through pmx_last_error()"""
+    rng = np.random.default_rng(9990)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = [random_seqs(rng, 1, L, L)[0] for L in (3000, 2500, 2100)]
+    rs = [mutate(rng, q, 0.1, 0.05) for q in qs]
+    qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+    for mode in (0, 1, 2):
+        al = _builder(pkg, pm, 5, 2, mode).build()
+        want = orc.align_batch(mode, qb, qo, rb, ro, 5, 2, om)
+        got = _rec(al.align_batch(qs, rs))
+        assert LONG in pkg.lib.pmx_last_kernel().decode()
+        assert (got == want).all()
+        with monkeypatch.context() as mp:
+            mp.setenv("PMX_LONG_SPIN_LIMIT", "0")
+            got0 = al.align_batch(qs, rs)
+            assert LONG not in pkg.lib.pmx_last_kernel().decode(), pkg.lib.pmx_last_kernel()
+            assert b"bounded wait" in pkg.lib.pmx_last_error()
+            assert (_rec(got0) == want).all() and (got0["flags"] == 0).all()
+        one = al.align(qs[0], rs[0])                                       # and the normal road is back
+        assert LONG in pkg.lib.pmx_last_kernel().decode() and one.get_score() == want[0, 0]
+
+
+@pytest.mark.timeout(300)
+def test_two_host_threads_run_long_grids_side_by_side(pkg, orc):
+    """(round-3 review) scratch and streams are per host thread, so two threads can have two long-pair grids on the chip at once,
+    each with spinning consumers: 2 x 600 pairs of 5 kbp oversubscribe the chip several times.  Both drain (the lowest unfinished
+    band of either grid is always resident) and every record equals the oracle's."""
+    import threading
+    rng = np.random.default_rng(9991)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    batches = []
+    for t in range(2):
+        qs = random_seqs(rng, 600, 4800, 5200)
+        rs = [mutate(rng, q, 0.08, 0.03) if k % 3 else random_seqs(rng, 1, 4000, 5200)[0] for k, q in enumerate(qs)]
+        batches.append((qs, rs))
+    al = _builder(pkg, pm, 5, 2, 2).build()
+    out, names, errs = [None, None], [None, None], []
+
+    def work(t):
+        try:
+            for _ in range(2):
+                out[t] = al.align_batch(*batches[t])
+                names[t] = pkg.lib.pmx_last_kernel().decode()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for t in range(2):
+        assert LONG in names[t], names
+        qs, rs = batches[t]
+        idx = np.arange(0, 600, 7)
+        qb, qo = orc.pack([qs[k] for k in idx]); rb, ro = orc.pack([rs[k] for k in idx])
+        want = orc.align_batch(2, qb, qo, rb, ro, 5, 2, om)
+        assert (_rec(out[t])[idx] == want).all() and (out[t]["flags"] == 0).all()
