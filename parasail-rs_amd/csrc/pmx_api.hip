@@ -2017,7 +2017,7 @@ static int banded_device(const pmx_config_t *cfg, int64_t n, const uint8_t *d_qb
     const char *kname = "pmx_banded_kernel";
     void *sort_scr = nullptr, *retry_scr = nullptr;
     if (n >= 4096 && n < (1LL << 32) && scratch_reserve(pmx_sort_scratch_bytes(n), &sort_scr, SCR_SORT)) return -1;
-    if (n < (1LL << 31) && scratch_reserve(((size_t)n + 1) * sizeof(unsigned), &retry_scr, SCR_RETRY)) return -1;
+    if (n < (1LL << 31) && scratch_reserve(2 * ((size_t)n + 1) * sizeof(unsigned), &retry_scr, SCR_RETRY)) return -1;      // two lists: wildcards, ties
     const int rcb = pmx_launch_banded(c.mode, c.sg_flags, c.open, c.extend, dm.d, n, d_qbuf, d_qoff, q_shared, d_rbuf, d_roff,
                                       max_qlen, max_rlen, band, d_diag, d_out, (hipStream_t)stream, &kname, sort_scr,
                                       retry_scr ? (unsigned *)retry_scr + 1 : nullptr, (int *)retry_scr);

@@ -82,7 +82,7 @@ struct SConst {
 template <int MODEV>
 __device__ __forceinline__ void s_init_of(const SGeo &p, const SConst &k, int d, bool col_pen, bool row_pen, int &hx, int &fn)
 {
-    constexpr bool SW = MODEV == 2;
+    constexpr bool SW = MODEV >= 2;
     constexpr int A_ = SW ? 1 : (MODEV == 1 ? 2 : 1), B_ = SW ? 0 : 1;
     const int Cg = k.open - k.ext;
     const int sig = (A_ * -1 + B_ * d) * k.ext;
@@ -109,7 +109,7 @@ __device__ __forceinline__ void s_init_of(const SGeo &p, const SConst &k, int d,
     fn = col_pen ? hx + Cg : hx;
 }
 
-template <int G, int C, int MODEV /* 0: nw / sg, one skew; 1: nw / sg, double skew; 2: sw */,
+template <int G, int C, int MODEV /* 0: nw / sg, one skew; 1: nw / sg, double skew; 2: sw; 3: sw, ties settled by a second launch */,
           int EPG /* > 0: that many leading cells carry a guard of their own; < 0: the first -EPG cells are ONE guarded block (the band starts at cell -EPG of the first live lane) */>
 __global__ __launch_bounds__(64)
 void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restrict__ qoff, int q_shared,
@@ -117,9 +117,14 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
                        const int16_t *__restrict__ gmat, const uint8_t *__restrict__ gmap, int msize,
                        SConst k, const int32_t *__restrict__ diag, const unsigned *__restrict__ perm,
                        int RC, int QC /* bytes per lane group: reference selectors, query letters (one shared query: QC bytes once) */,
-                       unsigned *__restrict__ retry_list, int *__restrict__ retry_count, pmx_record_t *__restrict__ out)
+                       unsigned *__restrict__ retry_list, int *__restrict__ retry_count,
+                       unsigned *__restrict__ tie_list, int *__restrict__ tie_count /* MODEV 3: pairs whose end cell a tie may move */,
+                       const int *__restrict__ n_dev /* != nullptr: the pair count is read from the device (the launch over tie_list) */,
+                       pmx_record_t *__restrict__ out)
 {
-    constexpr bool SW = MODEV == 2;
+    constexpr bool SW = MODEV >= 2, TIES_LATER = MODEV == 3;
+    if (n_dev) n = *n_dev;
+    if ((long long)blockIdx.x * (2 * (64 / G)) >= n) return;
     constexpr int A_ = SW ? 1 : (MODEV == 1 ? 2 : 1), B_ = SW ? 0 : 1;      // sigma = (A_ tau + B_ d) ext
     constexpr bool ESUB = B_ == 0, FSUB = A_ == B_;
     constexpr int SUBG = 16 / G, NG = 64 / G, NP = 2 * NG;
@@ -309,6 +314,7 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
     int browH[2] = {S_NEG, S_NEG}, browJ[2] = {0, 0}, bcolH[2] = {S_NEG, S_NEG}, bcolI[2] = {0, 0};
     int best = SW ? (k.bias - Cg) * 0x00010001 : 0;  // sw: the lane's best in the X form of its current row
     int bestrow = 0;                                 // sw: the row (relative, per half) that saved it
+    int tflag = 0;                                   // sw, ties settled later: bit 15 of a half = a tie with the lane's own best since it was saved
     int fake = -1;                                   // sw: halves whose `best` is not a score this lane has seen (the initial zero; a bound taken over from the group)
     int Hsave[SW ? C : 1];                           // sw: that row's strip
 #pragma unroll
@@ -422,7 +428,11 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
                     // ... and only while the saved cell is young: a later row wins a tie by an earlier COLUMN (tau + c), i.e. within C - 2 rows
                     const int age = (tau & 0xFFFF) * 0x00010001 - bestrow;
                     const int tie = (d2 - 0x00010001) & ~d2 & (int)0x80008000 & ~fake & (age - (C - 1) * 0x00010001);
-                    if (__builtin_amdgcn_ballot_w64(tie != 0) != 0) {
+                    // TIES_LATER: such a tie is only REMEMBERED (until the lane's next real improvement); a pair whose winning lane ends with one is
+                    // handed to a second launch of the exact variant -- related reads tie in most rows SOMEWHERE in a wave, and settling each on the
+                    // spot cost a quarter of the kernel
+                    if (TIES_LATER) tflag |= tie;
+                    else if (__builtin_amdgcn_ballot_w64(tie != 0) != 0) {
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const int r16 = h ? (int)((unsigned)rm >> 16) : (rm & 0xFFFF);
@@ -455,6 +465,7 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
                         }
                         best = s_max2(best, rm);
                         fake &= ~mgt;
+                        if (TIES_LATER) tflag &= ~mgt;
                     }
                     best += a2;
                     Zpe += a2;
@@ -547,6 +558,13 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
             { const int ot = __shfl_xor(st, lo, 64), oj = __shfl_xor(sj, lo, 64), oi = __shfl_xor(si, lo, 64);
               if (ot > st || (ot == st && (oj < sj || (oj == sj && oi < si)))) { st = ot; sj = oj; si = oi; } }
         }
+        int unsure = 0;
+        if (TIES_LATER) {
+            // (the packed tie test may flag a half next to a zero one: then a pair is redone for nothing, never the other way round)
+            unsure = (bestT[h] == st && st > 0 && ((h ? (tflag >> 16) : tflag) & 0x8000)) ? 1 : 0;
+#pragma unroll
+            for (int off = G / 2; off >= 1; off >>= 1) unsure |= __shfl_xor(unsure, SUBG * off, 64);
+        }
         if (g == 0 && p.have) {
             pmx_record_t rec; rec.flags = 0;
             if (SW) {
@@ -570,6 +588,9 @@ void pmx_bstrip_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restri
             if (gwild[2 * grp + h]) {
                 rec.flags = PMX_FLAG_RETRY16;
                 retry_list[atomicAdd(retry_count, 1)] = (unsigned)p.pair;
+            } else if (TIES_LATER && unsure && !p.miss) {
+                rec.flags = PMX_FLAG_RETRY16;
+                tie_list[atomicAdd(tie_count, 1)] = (unsigned)p.pair;
             }
             out[p.pair] = rec;
         }
@@ -638,16 +659,15 @@ void pmx_banded_retry(int mode, int sg_flags, int open, int ext, const PmxDevMat
                       int band, const int32_t *diag, const unsigned *list, const int *count, pmx_record_t *out, hipStream_t stream);
 
 template <int G, int C, int MODEV>
-static int bs_launch(int guard /* 0: one leading cell, 1: every cell, 2: the first 7 cells of <8,13> as one block */, long long n, const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
+static int bs_launch(int guard /* 0: one leading cell, 1: every cell, 2: the first 7 cells of <8,13> as one block */, unsigned blocks, const int *n_dev, long long n, const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
                      const PmxDevMatrix &m, const SConst &k, const int32_t *diag, const unsigned *perm, int RC, int QC, size_t lds,
                      unsigned *retry_list, int *retry_count, pmx_record_t *out, hipStream_t stream)
 {
-    constexpr int NP = 2 * (64 / G);
-    const unsigned blocks = (unsigned)((n + NP - 1) / NP);
 #define BS_GO(EPG) do { \
         if (lds > 48 * 1024) { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_bstrip_kernel<G, C, MODEV, EPG>), 150 * 1024); if (rc) return rc; } \
         hipLaunchKernelGGL((pmx_bstrip_kernel<G, C, MODEV, EPG>), dim3(blocks), dim3(64), lds, stream, qbuf, qoff, q_shared, rbuf, roff, n, \
-                           m.scores, m.mapper, m.msize, k, diag, perm, RC, QC, retry_list, retry_count, out); } while (0)
+                           m.scores, m.mapper, m.msize, k, diag, perm, RC, QC, retry_list, retry_count, \
+                           retry_list + n + 1, reinterpret_cast<int *>(retry_list + n), n_dev, out); } while (0)
     if (guard == 2) { if constexpr (G == 8 && C == 13) BS_GO(-7); else return 1; }
     else if (guard == 1) BS_GO(C); else BS_GO(1);
 #undef BS_GO
@@ -685,18 +705,28 @@ int pmx_launch_bstrip(int mode, int sg_flags, int open, int ext, const PmxDevMat
     // offsets in front of the band in the first live lane: one (the common case: capacity = band width + 1) has a guard of its own; <8,13>
     // with band 48 (7 cells = its whole left half: config 5's second pass) skips them as one block; anything else guards every cell
     const int guard_all = (eL % C) <= 1 ? 0 : (G == 8 && C == 13 && eL == 7 && !pmx_env("PMX_BSTRIP_CELL_GUARDS")) ? 2 : 1;
+    // scratch: [retry_count][retry_list: n][tie_count][tie_list: n]
+    int *tie_count = reinterpret_cast<int *>(retry_list + n);
     hipError_t e = hipMemsetAsync(retry_count, 0, sizeof(int), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(tie_count, 0, sizeof(int), stream);
     if (e != hipSuccess) return -(int)e;
     const unsigned *perm = nullptr;
     if (sort_scratch && n >= 4096) {
         const int rc = pmx_build_band_perm(qoff, q_shared, roff, diag, band, n, sort_scratch, &perm, stream, false);
         if (rc < 0) return rc;
     }
+    // local alignment: the first launch only REMEMBERS ties that could move an end cell (variant 3); the few pairs it is unsure of
+    // are redone by the exact variant (2), driven by the device-side count
+    const bool ties_later = modev == 2 && !pmx_env("PMX_BSTRIP_TIES_INLINE");
+    const unsigned blocks = (unsigned)((n + 2 * (64 / G) - 1) / (2 * (64 / G)));
     int rc = 1;
 #define BS_SHAPE(GG, CC) if (G == GG && C == CC) { \
-        rc = modev == 2 ? bs_launch<GG, CC, 2>(guard_all, n, qbuf, qoff, q_shared, rbuf, roff, m, k, diag, perm, RC, QC, lds, retry_list, retry_count, out, stream) \
-           : modev == 1 ? bs_launch<GG, CC, 1>(guard_all, n, qbuf, qoff, q_shared, rbuf, roff, m, k, diag, perm, RC, QC, lds, retry_list, retry_count, out, stream) \
-                        : bs_launch<GG, CC, 0>(guard_all, n, qbuf, qoff, q_shared, rbuf, roff, m, k, diag, perm, RC, QC, lds, retry_list, retry_count, out, stream); }
+        rc = modev == 2 ? (ties_later ? bs_launch<GG, CC, 3>(guard_all, blocks, nullptr, n, qbuf, qoff, q_shared, rbuf, roff, m, k, diag, perm, RC, QC, lds, retry_list, retry_count, out, stream) \
+                                      : bs_launch<GG, CC, 2>(guard_all, blocks, nullptr, n, qbuf, qoff, q_shared, rbuf, roff, m, k, diag, perm, RC, QC, lds, retry_list, retry_count, out, stream)) \
+           : modev == 1 ? bs_launch<GG, CC, 1>(guard_all, blocks, nullptr, n, qbuf, qoff, q_shared, rbuf, roff, m, k, diag, perm, RC, QC, lds, retry_list, retry_count, out, stream) \
+                        : bs_launch<GG, CC, 0>(guard_all, blocks, nullptr, n, qbuf, qoff, q_shared, rbuf, roff, m, k, diag, perm, RC, QC, lds, retry_list, retry_count, out, stream); \
+        if (rc == 0 && ties_later) \
+            rc = bs_launch<GG, CC, 2>(guard_all, blocks, tie_count, n, qbuf, qoff, q_shared, rbuf, roff, m, k, diag, retry_list + n + 1, RC, QC, lds, retry_list, retry_count, out, stream); }
     BS_SHAPE(1, 8) BS_SHAPE(1, 12) BS_SHAPE(1, 16) BS_SHAPE(2, 12) BS_SHAPE(2, 16) BS_SHAPE(4, 12) BS_SHAPE(4, 16) BS_SHAPE(8, 12) BS_SHAPE(8, 13) BS_SHAPE(8, 16) BS_SHAPE(4, 8) BS_SHAPE(8, 8)
 #undef BS_SHAPE
     if (rc) return rc;

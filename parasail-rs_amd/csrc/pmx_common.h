@@ -166,7 +166,7 @@ int pmx_launch_banded(int mode, int sg_flags, int open, int ext, const PmxDevMat
                       const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,
                       int max_qlen, int max_rlen, int band, const int32_t *diag, pmx_record_t *out, hipStream_t stream, const char **kernel_name = nullptr,
                       void *sort_scratch = nullptr /* pmx_sort_scratch_bytes(n) bytes: lets the packed forms pair up bands of equal length */,
-                      unsigned *retry_list = nullptr, int *retry_count = nullptr /* n entries + one int: lets the band-strip kernel hand pairs back */);
+                      unsigned *retry_list = nullptr, int *retry_count = nullptr /* [count][n entries] twice (retry_count first): lets the band-strip kernel hand pairs back */);
 // Band-strip kernel (pmx_bstrip.hip): band coordinates, packed int16, alphabets of <= 4 letters (+ wildcard).  Same contract.
 int pmx_launch_bstrip(int mode, int sg_flags, int open, int ext, const PmxDevMatrix &m, long long n,
                       const uint8_t *qbuf, const int64_t *qoff, int q_shared, const uint8_t *rbuf, const int64_t *roff,

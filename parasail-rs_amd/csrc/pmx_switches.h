@@ -52,6 +52,7 @@ struct PmxSwitchDoc { const char *name, *kind, *what; };
     X("PMX_BANDED_NO_STRIP",          "force", "banded, alphabets of <= 4 letters: the anti-diagonal kernels of pmx_banded.hip instead of the band-strip kernel (C offsets per lane)") \
     X("PMX_BSTRIP_SHAPE",             "value", "band-strip kernel: lanes per pair x offsets per lane, e.g. 4x8 (ignored unless that shape exists and holds the band)") \
     X("PMX_BSTRIP_CELL_GUARDS",       "force", "band-strip kernel <8,13>, band 48: a guard per cell instead of the guarded block in front of the band") \
+    X("PMX_BSTRIP_TIES_INLINE",       "force", "band-strip kernel, local alignment: ties that could move an end cell are settled where they occur (one launch) instead of remembered and redone by a second launch") \
     X("PMX_BSTRIP_ONE_SKEW",          "force", "band-strip kernel, global / semi-global: one skew (F pays a subtraction per cell) instead of the double skew") \
     X("PMX_BANDED_NO_PACKED",         "force", "banded local alignment: the 32-bit staged kernel instead of the packed int16 kernel (two pairs per lane group)") \
     X("PMX_BANDED_NO_ROWPERM",        "force", "packed banded kernel, alphabets of <= 7 letters: one LDS byte lookup per cell instead of the 8-byte matrix row + v_perm") \

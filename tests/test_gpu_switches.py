@@ -16,9 +16,12 @@ from util import random_seqs, mutate, DNA, AA
 pytestmark = pytest.mark.gpu
 
 # switches whose alternative is only reachable together with another one (the partner is set too)
-PARTNERS = {"PMX_STATS_BY_TRACE_ANY": ["PMX_STATS_BY_TRACE"]}
+PARTNERS = {"PMX_STATS_BY_TRACE_ANY": ["PMX_STATS_BY_TRACE"],
+            # forms of the anti-diagonal packed band kernel: reachable once the band-strip kernel is switched off
+            "PMX_BANDED_NO_ROWPERM": ["PMX_BANDED_NO_STRIP"], "PMX_BANDED_NO_SHARED_ROWS": ["PMX_BANDED_NO_STRIP"]}
 VALUES = {"PMX_SW16_VARIANT": ["0", "1", "2"], "PMX_STATS_CHUNK_BYTES": ["3e6"], "PMX_CIGAR_CHUNK_BYTES": ["3e6"],
-          "PMX_GENERAL_CHUNK_BYTES": ["1"], "PMX_LONG_CHUNK_BYTES": ["1e6"]}                      # (its batches: tests/test_gpu_tables.py)
+          "PMX_GENERAL_CHUNK_BYTES": ["1"], "PMX_LONG_CHUNK_BYTES": ["1e6"],
+          "PMX_BSTRIP_SHAPE": ["8x8", "2x16"], "PMX_LONG_SPIN_LIMIT": ["0"]}                      # (its batches: tests/test_gpu_tables.py)
 NOT_A_DISPATCH_CHOICE = {"PMX_MATRIX_DIR", "PMX_TIMING", "PMX_CIGAR_SWAP_ID"}          # a path (tests/test_abi.py) and a diagnostics print
 
 
@@ -124,6 +127,8 @@ def _suite(pkg, orc):
     bdg = np.array([len(bpre[k]) - k % 100 + k % 7 - 3 for k in range(300)], dtype=np.int32)
     albp = builder(dna_p, 5, 2, "sw").profile(pkg.Profile.new(bq, False, dna_p)).build()
     cases.append(("sw/dna/banded shared query", lambda: (rec(albp.align_batch_banded([], brs, 20, bdg)),)))
+    cases.append(("sw/dna/banded48", lambda: (rec(albs.align_batch_banded(dq[:300], dr[:300], 48)),)))   # <8,13>: seven offsets in front of the band
+    cases.append(("sg/dna/banded48", lambda: (rec(builder(dna_p, 5, 2, "sg").build().align_batch_banded(dq[:300], dr[:300], 48)),)))
     alt = builder(dna_p, 5, 2, "sg").use_table().build()
 
     def table():
@@ -213,5 +218,6 @@ def test_every_switch_is_result_neutral(pkg, orc, monkeypatch):
         inert.append(env) if not changed else None
     # a switch that reroutes nothing here would be tested in name only (chunk sizes and variant caps change no kernel name)
     same_name = set(VALUES) | {"PMX_CIGAR_NO_OVERLAP", "PMX_STATS_NO_OVERLAP", "PMX_TRACE_NO_BFI", "PMX_TRACE_FETCH",      # another instance / schedule of one kernel
+                               "PMX_BSTRIP_TIES_INLINE", "PMX_BSTRIP_CELL_GUARDS",
                                "PMX_NO_FAST_TABLE", "PMX_GENERAL_ONE_WAVE", "PMX_NWSGQ_ENDS_ALWAYS", "PMX_STATS_EQUAL_CHUNKS", "PMX_STATS_NO_SHORT_TAIL"}                       # (single calls do not record a name)
     assert all(any(k in same_name for k in env) for env in inert), inert
