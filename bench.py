@@ -76,6 +76,13 @@ def valu_ceiling(kernel):
     return None, None
 
 
+def valu_instructions_per_128(kernel):
+    for key in sorted(VALU_MODEL, key=len, reverse=True):
+        if key.split("/")[0] in kernel and all(p in kernel for p in key.split("/")[1:]):
+            return VALU_MODEL[key][0] + VALU_MODEL[key][1]
+    return None
+
+
 def usable_cores():
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     cores = os.cpu_count() or 1
@@ -539,11 +546,13 @@ class Cfg5(Workload):
         kept = float((d_out[:, 0] == rec[:, 0]).float().mean().item())
         return {"banded_sw": {"band": band, "ms": round(ms, 3), "pairs_per_s": round(self.n / (ms * 1e-3)),
                               "band_gcups": round(band_cells / (ms * 1e-3) / 1e9, 1),
-                              "full_matrix_equivalent_gcups": round(self.cells / (ms * 1e-3) / 1e9, 1),
+                              "band_cells_inside_the_matrix": int(band_cells),
                               "kernel": self.pkg.lib.pmx_last_kernel().decode(),
                               "never_above_full_pass": same, "share_of_pairs_with_the_full_score": round(kept, 4),
                               "note": "extension, no reference counterpart: |(j - i) - diag| <= band with diag = end_ref - end_query of "
-                                      "the first pass; only the band's cells are computed (packed int16 lanes, two pairs per lane group)"}}
+                                      "the first pass; only the band's cells are computed and only they are counted (band-strip kernel: band "
+                                      "coordinates, 13 offsets per lane, packed int16, two pairs per lane group; the sort by band length and "
+                                      "the second launch that settles end-cell ties are inside the time)"}}
 
     def cpu_baseline(self, last_out):
         from oracle import oracle as orc
@@ -682,7 +691,9 @@ def run_config(env, config, steps, warmup, scaling, pairs, cpu_legs=True, deferr
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc.get("traffic") if pmc else None,
                          "traffic_source": pmc.get("source") if pmc else None,
                          "traffic_over_algorithmic": round(pmc["traffic"] / w.algo_bytes, 2) if pmc and pmc.get("traffic") else None,
-                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": int(w.algo_bytes),
+                         "kernel_ms": round(kern_ms, 4), "kernel_ms_clock": "HIP events around each step on the launch stream, inside bench.py "
+                                                                           "(the rocprofv3 average of the same kernel under profiles/ is ~4 % longer: profiler overhead)",
+                         "algorithmic_bytes": int(w.algo_bytes),
                          "note": w.algo_note + "; the path is VALU-bound, see roofline_valu"},
         }
         if pmc and "lds_bank_conflict" in pmc:
@@ -695,6 +706,14 @@ def run_config(env, config, steps, warmup, scaling, pairs, cpu_legs=True, deferr
                                      "frac": round(kern_gcups / peak, 4), "model": model}
             if pmc and "valu_issue" in pmc:
                 line["roofline_valu"]["measured"] = dict(pmc["valu_issue"], source=pmc["source"])
+                # the 4 / 2-cycle model above is optimistic for this VOP3P / VOP2 mix (profiles/r01/valu_rate_microbench.txt: a 1:1 mix
+                # issues at ~3.9 cycles per instruction): the same instruction count at the issue rate the counters measured
+                v3v2 = valu_instructions_per_128(kernel)
+                if v3v2:
+                    cpi = pmc["valu_issue"]["cycles_per_valu_instruction_per_simd"]
+                    pk = SIMD_CYCLES_PER_S / (v3v2 * cpi) * 128.0 / 1e9
+                    line["roofline_valu"]["peak_at_measured_issue_rate"] = round(pk, 1)
+                    line["roofline_valu"]["frac_at_measured_issue_rate"] = round(kern_gcups / pk, 4)
         if multi and world == 1:
             # rehearsal of the exchange path with one rank (PMX_BENCH_FORCE_DIST): what rank 0 gathered must be what it computed
             line["exchange_check"] = w.check_exchange(env.last_gather) if hasattr(w, "check_exchange") else \
@@ -710,6 +729,16 @@ def run_config(env, config, steps, warmup, scaling, pairs, cpu_legs=True, deferr
             if world == 1 and cpu_legs:
                 line["cpu_baseline"] = w.cpu_baseline(last_out)
         if deferred is not None:
+            # the host legs run after every config's GPU steps: they need the host inputs only -- the device buffers go now, so that the
+            # next config is timed in the memory state `--config N` alone would see (the library sizes its chunks from hipMemGetInfo)
+            for name, val in list(vars(w).items()):             # inputs (`d`) are dropped, the last outputs move to host memory
+                if torch.is_tensor(val) and val.is_cuda:
+                    setattr(w, name, None if name == "d" else val.cpu())
+                elif isinstance(val, (list, tuple)) and val and all(torch.is_tensor(x) and x.is_cuda for x in val):
+                    setattr(w, name, None if name == "d" else [x.cpu() for x in val])
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
             deferred.append(host_legs)
             return line
         host_legs()
@@ -798,6 +827,13 @@ def main():
             import gc
             gc.collect()
     if rank == 0:
+        if line.get("configs"):
+            # the numbers of every config once more at the END of the line (a log tail keeps the end)
+            line["summary"] = {"2": {"gcups": line["value"], "ms_per_step": line["ms_per_step"]}}
+            for c, sub in line["configs"].items():
+                line["summary"][c] = {"gcups": sub.get("value"), "ms_per_step": sub.get("ms_per_step")}
+                if "banded_sw" in sub:
+                    line["summary"][c]["banded_second_pass_ms"] = sub["banded_sw"]["ms"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -33,7 +33,7 @@ for mode, name in ((pkg.MODE_NW, "nw"), (pkg.MODE_SG, "sg"), (pkg.MODE_SW, "sw")
     full = out.clone()
     print("%s full matrix            %8.3f ms  %8.1f GCUPS  %s" % (name, ms, n * 62500 / ms / 1e6, pkg.lib.pmx_last_kernel().decode()), flush=True)
     for band in (15, 31, 48):
-        for env in (None, "PMX_BSTRIP_ONE_SKEW", "PMX_BANDED_NO_STRIP"):
+        for env in (None, "PMX_BANDED_NO_STRIP"):
             if env:
                 os.environ[env] = "1"
             def run():

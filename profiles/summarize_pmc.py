@@ -32,7 +32,8 @@ def kernel_source(kernel):
 
 def source_blobs(kernel):
     src = kernel_source(kernel)
-    files = [f for f in (src,) if f and os.path.exists(f)]
+    # the dispatcher and the shared header too: an edit to the chunking changes launches_per_step under the same kernel name
+    files = [f for f in (src, os.path.join(CSRC, "pmx_api.hip"), os.path.join(CSRC, "pmx_common.h")) if f and os.path.exists(f)]
     return {os.path.basename(f): git_blob_id(f) for f in files}
 
 
