@@ -32,7 +32,7 @@ class _Outputs(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("pmx_oracle.c", "pmx_oracle_batch.c", "pmx_striped_cpu.c", "pmx_striped_body.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("pmx_oracle.c", "pmx_oracle_batch.c", "pmx_striped_cpu.c", "pmx_cpu_inter16.c", "pmx_striped_body.h", "Makefile")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -59,6 +59,8 @@ def lib():
         _lib.orc_cigar_sample.restype = C.c_int
         _lib.orc_rescore_cigars.restype = C.c_long
         _lib.orc_align_banded_batch.restype = C.c_int
+        _lib.pmx_cpu_nw_stats_inter16.restype = C.c_int
+        _lib.pmx_cpu_trace_cigar_inter16.restype = C.c_int
     return _lib
 
 
@@ -316,3 +318,36 @@ def align_banded_batch(mode, qbuf, qoff, rbuf, roff, open_, ext, matrix, band, d
     if rc:
         raise RuntimeError("orc_align_banded_batch: some pair failed")
     return out
+
+
+def cpu_nw_stats_inter16(query, rbuf, roff, open_, ext, matrix, threads=0):
+    """Vectorised CPU restatement of `nw_stats_*_profile_16` (one shared query; 16 references per AVX2 vector: pmx_cpu_inter16.c)
+    -> (int32 [n, 6]: score, end_query, end_ref, matches, similar, length; threads used)."""
+    n = len(roff) - 1
+    out = np.zeros((n, 6), dtype=np.int32)
+    qb = np.frombuffer(bytes(query), dtype=np.uint8)
+    roff = np.ascontiguousarray(roff, dtype=np.int64)
+    used = lib().pmx_cpu_nw_stats_inter16(C.c_long(n), _ptr(qb), len(qb), _ptr(rbuf), _ptr(roff), int(open_), int(ext),
+                                          _ptr(matrix.scores), matrix.size, _ptr(matrix.mapper), _ptr(out), int(threads))
+    if used < 0:
+        raise RuntimeError("pmx_cpu_nw_stats_inter16 failed (%d)" % used)
+    return out, used
+
+
+def cpu_trace_cigar_inter16(mode, qbuf, qoff, rbuf, roff, open_, ext, matrix, threads=0, decode=True):
+    """Vectorised CPU restatement of `{nw,sg}_trace_*_16` + get_cigar (16 pairs per AVX2 vector, byte trace table, scalar walk;
+    semi-global = all four ends free; match / mismatch matrices only) -> (list of CIGAR texts, int32 [n, 5]: score, end_query,
+    end_ref, beg_query, beg_ref; threads used)."""
+    n = len(roff) - 1
+    qoff = np.ascontiguousarray(qoff, dtype=np.int64); roff = np.ascontiguousarray(roff, dtype=np.int64)
+    stride = int(max(16, 2 * (int(np.max(qoff[1:] - qoff[:-1])) + int(np.max(roff[1:] - roff[:-1]))) + 16))
+    text = np.zeros((n, stride), dtype=np.uint8)
+    rec = np.zeros((n, 5), dtype=np.int32)
+    used = lib().pmx_cpu_trace_cigar_inter16(1 if mode == SG else 0, C.c_long(n), _ptr(qbuf), _ptr(qoff), _ptr(rbuf), _ptr(roff),
+                                             int(open_), int(ext), _ptr(matrix.scores), matrix.size, _ptr(matrix.mapper),
+                                             _ptr(text), stride, _ptr(rec), int(threads))
+    if used < 0:
+        raise RuntimeError("pmx_cpu_trace_cigar_inter16 failed (%d)" % used)
+    blob = text.tobytes()                                    # (NUL-terminated slots: one split per pair, outside any timed region)
+    texts = [blob[k * stride:(k + 1) * stride].split(b"\0", 1)[0] for k in range(n)] if decode else text
+    return texts, rec, used

@@ -182,3 +182,34 @@ def test_cfg1_fixture_is_reproduced(orc):
         assert (w.score, w.end_query, w.end_ref, w.matches, w.similar, w.length) == \
             (c["score"], c["end_query"], c["end_ref"], c["matches"], c["similar"], c["length"])
         assert orc.cigar(w) == c["cigar"]
+
+
+def test_vectorised_cpu_ports_of_the_stats_and_trace_modes(orc):
+    """oracle/pmx_cpu_inter16.c (the CPU timing baselines of BASELINE configs 3 and 4: 16 pairs per AVX2 vector) against the scalar
+    oracle, bit for bit: score, ends, matches / similar / length of `nw_stats_*_profile_16` with one shared protein query, ragged
+    references; score, ends, begin positions and CIGAR text of `sg_trace` / `nw_trace` on DNA with ragged pairs, tie-heavy gap
+    models and wildcards."""
+    from util import AA
+    rng = np.random.default_rng(4242)
+    b62 = orc.Matrix.from_file("tests/golden/blosum62.txt")
+    for qlen, n, lo, hi, o, e in ((300, 45, 380, 520, 11, 1), (37, 33, 1, 90, 3, 3), (120, 17, 100, 140, 5, 0)):
+        q = random_seqs(rng, 1, qlen, qlen, AA)[0]
+        rs = [mutate(rng, q, 0.3, 0.05, AA) + random_seqs(rng, 1, 0, 60, AA)[0] if k % 2 else random_seqs(rng, 1, lo, hi, AA)[0] for k in range(n)]
+        rb, ro = orc.pack(rs)
+        got, used = orc.cpu_nw_stats_inter16(q, rb, ro, o, e, b62, threads=2)
+        want = orc.align_stats_sample(orc.NW, np.arange(n), None, None, rb, ro, o, e, b62, shared_query=q)
+        assert used >= 1 and (got == want[:, :6]).all(), (qlen, np.nonzero((got != want[:, :6]).any(axis=1))[0][:5], got[:3], want[:3])
+    dna = orc.Matrix.create("ACGT", 2, -3)
+    for mode in (orc.SG, orc.NW):
+        for n, lo, hi, o, e in ((50, 1, 40, 5, 2), (35, 200, 260, 5, 2), (40, 10, 120, 2, 2), (33, 30, 90, 4, 0)):
+            qs = random_seqs(rng, n, lo, hi)
+            rs = [mutate(rng, q, 0.1, 0.05) if k % 3 else random_seqs(rng, 1, lo, hi)[0] for k, q in enumerate(qs)]
+            qs[1] = qs[1][:1] + b"N" + qs[1][2:] if len(qs[1]) > 2 else qs[1]
+            rs[2] = rs[2][:1] + b"N" + rs[2][2:] if len(rs[2]) > 2 else rs[2]
+            qb, qo = orc.pack(qs); rb, ro = orc.pack(rs)
+            texts, rec, used = orc.cpu_trace_cigar_inter16(mode, qb, qo, rb, ro, o, e, dna, threads=2)
+            wtext, wrec = orc.cigar_sample(mode, np.arange(n), qb, qo, rb, ro, o, e, dna)
+            assert (rec == wrec).all(), (mode, n, np.nonzero((rec != wrec).any(axis=1))[0][:5], rec[:3], wrec[:3])
+            assert [t.decode() for t in texts] == wtext, (mode, n)
+    with pytest.raises(RuntimeError):                       # not a match / mismatch matrix: refused, not mis-scored
+        orc.cpu_trace_cigar_inter16(orc.SG, qb, qo, rb, ro, 11, 1, b62)
