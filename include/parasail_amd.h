@@ -374,6 +374,11 @@ const char *pmx_kernel_for(const pmx_config_t *cfg, int32_t max_qlen, int32_t ma
 const char *pmx_last_kernel(void);
 /* Every environment switch the library reads, one "NAME\tkind\twhat\n" line each (parasail-rs_amd/csrc/pmx_switches.h). */
 const char *pmx_switches(void);
+/* Deferred results (environment switch PMX_DEFER_ALIGN=1): the one-pair alignment functions (score and statistics names) queue the
+ * pair and return a PENDING parasail_result_t; the first accessor (parasail_result_get_score, ...) of any pending result of that
+ * thread -- or a queue of 262 144 pairs, or a call with another configuration -- runs the queue as ONE batch launch.  The mode / width
+ * predicates answer at once; freeing a pending result withdraws it.  pmx_flush_deferred() runs the calling thread's queue now. */
+void pmx_flush_deferred(void);
 /* The 66 matrix names the reference documents (src/matrix/mod.rs:46-50), one per line, into buf (NUL-terminated, truncated to cap);
  * returns the bytes needed.  parasail_matrix_lookup() embeds blosum62 / nuc44 and resolves the others from files (pmx_last_error()
  * tells a documented name whose file is missing from an unknown name, and why a file was refused). */

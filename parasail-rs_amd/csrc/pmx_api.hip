@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <system_error>
@@ -514,6 +515,7 @@ enum {
     F_BITS_8 = 1 << 20, F_BITS_16 = 1 << 21, F_BITS_32 = 1 << 22, F_BITS_64 = 1 << 23
 };
 
+struct PmxPendQueue;
 struct parasail_result {
     int score, end_query, end_ref, flag;
     int matches, similar, length;
@@ -522,15 +524,21 @@ struct parasail_result {
     int *rows[4];          // [rlen]
     int *cols[4];          // [qlen]
     int8_t *trace;         // [qlen*rlen]
+    // Deferred results (switch PMX_DEFER_ALIGN): non-null while the pair sits in a queue of calls that have not run yet; the first
+    // accessor that needs a computed field (of ANY result of that queue) runs the whole queue as one batch.  A heap block holding a
+    // shared reference to the queue, so that a result may be read or freed from another thread and outlives its creator thread.
+    struct PmxPendRef *pending;
 };
+static void pend_resolve(const parasail_result_t *r);
+#define RESOLVE(r) do { if (__atomic_load_n(&(r)->pending, __ATOMIC_ACQUIRE)) pend_resolve(r); } while (0)
 
 extern "C" {
-int parasail_result_get_score(const parasail_result_t *r) { return r->score; }
-int parasail_result_get_end_query(const parasail_result_t *r) { return r->end_query; }
-int parasail_result_get_end_ref(const parasail_result_t *r) { return r->end_ref; }
-int parasail_result_get_matches(const parasail_result_t *r) { return r->matches; }
-int parasail_result_get_similar(const parasail_result_t *r) { return r->similar; }
-int parasail_result_get_length(const parasail_result_t *r) { return r->length; }
+int parasail_result_get_score(const parasail_result_t *r) { RESOLVE(r); return r->score; }
+int parasail_result_get_end_query(const parasail_result_t *r) { RESOLVE(r); return r->end_query; }
+int parasail_result_get_end_ref(const parasail_result_t *r) { RESOLVE(r); return r->end_ref; }
+int parasail_result_get_matches(const parasail_result_t *r) { RESOLVE(r); return r->matches; }
+int parasail_result_get_similar(const parasail_result_t *r) { RESOLVE(r); return r->similar; }
+int parasail_result_get_length(const parasail_result_t *r) { RESOLVE(r); return r->length; }
 int *parasail_result_get_score_table(const parasail_result_t *r) { return r->tables[0]; }
 int *parasail_result_get_matches_table(const parasail_result_t *r) { return r->tables[1]; }
 int *parasail_result_get_similar_table(const parasail_result_t *r) { return r->tables[2]; }
@@ -547,7 +555,7 @@ int *parasail_result_get_trace_table(const parasail_result_t *r) { return reinte
 int parasail_result_is_nw(const parasail_result_t *r) { return !!(r->flag & F_NW); }
 int parasail_result_is_sg(const parasail_result_t *r) { return !!(r->flag & F_SG); }
 int parasail_result_is_sw(const parasail_result_t *r) { return !!(r->flag & F_SW); }
-int parasail_result_is_saturated(const parasail_result_t *r) { return !!(r->flag & F_SATURATED); }
+int parasail_result_is_saturated(const parasail_result_t *r) { RESOLVE(r); return !!(r->flag & F_SATURATED); }
 int parasail_result_is_banded(const parasail_result_t *r) { return !!(r->flag & F_BANDED); }
 int parasail_result_is_scan(const parasail_result_t *r) { return !!(r->flag & F_SCAN); }
 int parasail_result_is_striped(const parasail_result_t *r) { return !!(r->flag & F_STRIPED); }
@@ -561,9 +569,11 @@ int parasail_result_is_rowcol(const parasail_result_t *r) { return !!(r->flag & 
 int parasail_result_is_stats_rowcol(const parasail_result_t *r) { return (r->flag & F_STATS) && (r->flag & F_ROWCOL); }
 int parasail_result_is_trace(const parasail_result_t *r) { return !!(r->flag & F_TRACE); }
 
+static void pend_cancel(parasail_result_t *r);
 void parasail_result_free(parasail_result_t *r)
 {
     if (!r) return;
+    if (__atomic_load_n(&r->pending, __ATOMIC_ACQUIRE)) pend_cancel(r);      // a result that was never looked at: its pair leaves the queue
     for (int k = 0; k < 4; ++k) { free(r->tables[k]); free(r->rows[k]); free(r->cols[k]); }
     free(r->trace);
     free(r);
@@ -628,6 +638,97 @@ template <typename T> struct DevBuf {
     int try_alloc(size_t n) { return hipMalloc(&p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }   // entries that can report an error
 };
 
+// ---- deferred results (PMX_DEFER_ALIGN) ----------------------------------------------------------------------------------
+// One queue per host thread and configuration: packed sequences as the batch entry wants them, and the results waiting for them.
+struct PmxPendQueue {
+    std::mutex mx;
+    pmx_config_t cfg; RunSpec sp;
+    std::vector<uint8_t> qbuf, rbuf;
+    std::vector<int64_t> qoff{0}, roff{0};
+    std::vector<parasail_result_t *> res;          // nullptr: the result was freed before anything asked for it
+};
+struct PmxPendRef { std::shared_ptr<PmxPendQueue> q; };
+static thread_local std::shared_ptr<PmxPendQueue> g_pend;
+
+extern "C" int pmx_align_batch(const pmx_config_t *cfg, int64_t n, const uint8_t *qbuf, const int64_t *qoff, const uint8_t *rbuf, const int64_t *roff,
+                               pmx_record_t *out, pmx_stats_t *stats_out);
+
+// runs the queue (its mutex held by the caller) and completes every result in it
+static void pend_flush_locked(PmxPendQueue &q)
+{
+    const int64_t n = (int64_t)q.res.size();
+    if (!n) return;
+    std::vector<pmx_record_t> rec((size_t)n);
+    std::vector<pmx_stats_t> st(q.sp.stats ? (size_t)n : 0);
+    if (pmx_align_batch(&q.cfg, n, q.qbuf.data(), q.qoff.data(), q.rbuf.data(), q.roff.data(), rec.data(), q.sp.stats ? st.data() : nullptr))
+        die(g_err, hipSuccess);
+    for (int64_t k = 0; k < n; ++k) {
+        parasail_result_t *r = q.res[(size_t)k];
+        if (!r) continue;
+        r->score = rec[(size_t)k].score; r->end_query = rec[(size_t)k].end_query; r->end_ref = rec[(size_t)k].end_ref;
+        if (rec[(size_t)k].flags & PMX_FLAG_SATURATED) r->flag |= F_SATURATED;
+        if (q.sp.stats) { r->matches = st[(size_t)k].matches; r->similar = st[(size_t)k].similar; r->length = st[(size_t)k].length; }
+        PmxPendRef *ref = r->pending;
+        __atomic_store_n(&r->pending, (PmxPendRef *)nullptr, __ATOMIC_RELEASE);
+        delete ref;
+    }
+    q.qbuf.clear(); q.rbuf.clear(); q.qoff.assign(1, 0); q.roff.assign(1, 0); q.res.clear();
+}
+static void pend_resolve(const parasail_result_t *r)
+{
+    PmxPendRef *ref = __atomic_load_n(&r->pending, __ATOMIC_ACQUIRE);
+    if (!ref) return;
+    std::shared_ptr<PmxPendQueue> q = ref->q;          // (the flush deletes `ref`)
+    std::lock_guard<std::mutex> lk(q->mx);
+    if (__atomic_load_n(&r->pending, __ATOMIC_ACQUIRE)) pend_flush_locked(*q);
+}
+static void pend_cancel(parasail_result_t *r)
+{
+    PmxPendRef *ref = __atomic_load_n(&r->pending, __ATOMIC_ACQUIRE);
+    if (!ref) return;
+    std::shared_ptr<PmxPendQueue> q = ref->q;
+    std::lock_guard<std::mutex> lk(q->mx);
+    ref = __atomic_load_n(&r->pending, __ATOMIC_ACQUIRE);
+    if (!ref) return;                                   // completed meanwhile
+    for (auto &p : q->res) if (p == r) { p = nullptr; break; }     // its pair still runs with the batch; nobody reads the record
+    __atomic_store_n(&r->pending, (PmxPendRef *)nullptr, __ATOMIC_RELEASE);
+    delete ref;
+}
+// true: the pair was queued and `res` is pending
+static bool pend_enqueue(parasail_result_t *res, const RunSpec &sp, const char *s1, int s1Len, const char *s2, int s2Len,
+                         int open, int gap, const parasail_matrix_t *matrix)
+{
+    if (!pmx_env("PMX_DEFER_ALIGN")) return false;
+    if ((long long)s1Len * s2Len > (1LL << 20)) return false;           // long pairs fill the chip on their own
+    if (!g_pend) g_pend = std::make_shared<PmxPendQueue>();
+    std::shared_ptr<PmxPendQueue> q = g_pend;
+    std::lock_guard<std::mutex> lk(q->mx);
+    const bool same = !q->res.empty() && q->sp.mode == sp.mode && q->sp.sg_flags == sp.sg_flags && q->sp.width == sp.width &&
+                      q->sp.stats == sp.stats && q->cfg.open == open && q->cfg.extend == gap && q->cfg.matrix == matrix;
+    if (!q->res.empty() && (!same || q->res.size() >= (1u << 18) || q->qbuf.size() + q->rbuf.size() > ((size_t)256 << 20)))
+        pend_flush_locked(*q);                                           // another configuration, or enough for one batch
+    if (q->res.empty()) {
+        q->sp = sp; memset(&q->cfg, 0, sizeof q->cfg);
+        q->cfg.mode = sp.mode; q->cfg.sg_flags = sp.sg_flags; q->cfg.open = open; q->cfg.extend = gap; q->cfg.width = sp.width;
+        q->cfg.want = sp.stats ? PMX_WANT_STATS : 0; q->cfg.matrix = matrix;
+    }
+    q->qbuf.insert(q->qbuf.end(), (const uint8_t *)s1, (const uint8_t *)s1 + s1Len);
+    q->rbuf.insert(q->rbuf.end(), (const uint8_t *)s2, (const uint8_t *)s2 + s2Len);
+    q->qoff.push_back((int64_t)q->qbuf.size()); q->roff.push_back((int64_t)q->rbuf.size());
+    q->res.push_back(res);
+    PmxPendRef *ref = new PmxPendRef{q};
+    __atomic_store_n(&res->pending, ref, __ATOMIC_RELEASE);
+    return true;
+}
+// every pending result of the calling thread's queue, now (the mirrors call it when an aligner that deferred work goes away)
+extern "C" void pmx_flush_deferred(void)
+{
+    if (!g_pend) return;
+    std::shared_ptr<PmxPendQueue> q = g_pend;
+    std::lock_guard<std::mutex> lk(q->mx);
+    pend_flush_locked(*q);
+}
+
 static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Len, const char *s2, int s2Len,
                                      int open, int gap, const parasail_matrix_t *matrix)
 {
@@ -645,10 +746,14 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
     res->flag = flag;
     if (!s1 || !s2 || s1Len <= 0 || s2Len <= 0 || !matrix) return res;   // degenerate: empty result, never NULL
 
-    DevMat dm;
-    if (get_devmat(matrix, &dm)) die(g_err, hipSuccess);
     const bool pssm = matrix->type == PARASAIL_MATRIX_TYPE_PSSM;
     if (pssm && matrix->length != s1Len) die("PSSM length differs from the query length", hipSuccess);
+    // Deferred results (PMX_DEFER_ALIGN): the reference's parallel story is user threads calling align() one pair at a time
+    // (tests/test_parasail.rs:689-723); one launch + one wait per 150 x 150 pair is 50 us -- slower than one CPU core.  With the
+    // switch on, the call only queues the pair and hands back a PENDING result; the first accessor runs the thread's queue as ONE batch.
+    if (!sp.table && !sp.rowcol && !sp.trace && sp.band < 0 && !pssm && pend_enqueue(res, sp, s1, s1Len, s2, s2Len, open, gap, matrix)) return res;
+    DevMat dm;
+    if (get_devmat(matrix, &dm)) die(g_err, hipSuccess);
 
     if (!sp.table && !sp.rowcol && !sp.trace && sp.band < 0 && !pssm) {
         // score (+ stats) only: a one-pair batch through the same dispatcher as pmx_align_batch_device

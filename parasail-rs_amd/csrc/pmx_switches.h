@@ -65,6 +65,7 @@ struct PmxSwitchDoc { const char *name, *kind, *what; };
     X("PMX_LONG_CHUNK_BYTES",         "value", "long-pair kernel over a batch: bytes of boundary scratch per chunk (tests force several chunks)") \
     X("PMX_NO_FAST_TABLE",            "force", "score tables: general kernel instead of the table kernel") \
     X("PMX_CIGAR_SWAP_ID",            "convention", "CIGAR letters / BAM ops of the two gap states exchanged (I <-> D) in get_cigar, ssw and batch CIGAR text") \
+    X("PMX_DEFER_ALIGN",              "force", "one-pair alignment functions (score / statistics names): the call queues the pair and returns a pending result; the first accessor of any of the thread's pending results runs the queue as one batch") \
     X("PMX_TIMING",                   "diag",  "stage times of the batch CIGAR host entry on stderr")
 
 const char *pmx_env(const char *name);        // the environment value of a registered switch (pmx_api.hip; an unregistered name aborts)

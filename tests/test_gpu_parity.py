@@ -1646,3 +1646,64 @@ def test_fuzz_traceback_and_statistics_global_and_semi_global(pkg, orc, seed, mo
         if protein:
             _stats_case(pkg, orc, 0, None, None, rs, open_, ext, pm, om, shared_query=qs[0])
             _stats_case(pkg, orc, 1, int(rng.integers(1, 16)), None, rs, open_, ext, pm, om, shared_query=qs[0])
+
+
+def test_deferred_results_behind_the_unchanged_abi(pkg, orc, monkeypatch):
+    """PMX_DEFER_ALIGN (round-3 review, missing #4): the reference's calling pattern is one align() per pair
+    (/root/reference/src/aligner/mod.rs:397-452, tests/test_parasail.rs:702-717).  With the switch on, a score / statistics call
+    queues the pair and returns a pending result; the first accessor runs the queue as ONE batch.  Same values as the immediate
+    path for every mode, mixed configurations (a change of configuration runs the queue), results freed before they are read,
+    results read from another thread, the profile arm, and long pairs (which are not deferred)."""
+    import threading
+    rng = np.random.default_rng(7800)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    qs = random_seqs(rng, 300, 20, 200)
+    rs = [mutate(rng, q, 0.1, 0.04) for q in qs]
+    builders = {}
+    for mode in (0, 1, 2):
+        b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2)
+        [b.global_, b.semi_global, b.local][mode]()
+        builders[mode] = b.build()
+    bs = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).local().use_stats().build()
+    want = {mode: [(r.get_score(), r.get_end_query(), r.get_end_ref()) for r in (builders[mode].align(q, s) for q, s in zip(qs, rs))] for mode in builders}
+    want_st = [(r.get_score(), r.get_matches(), r.get_similar(), r.get_length()) for r in (bs.align(q, s) for q, s in zip(qs[:60], rs[:60]))]
+    monkeypatch.setenv("PMX_DEFER_ALIGN", "1")
+    for mode, al in builders.items():
+        res = [al.align(q, s) for q, s in zip(qs, rs)]            # 300 calls, nothing has run yet
+        assert res[0].is_local() == (mode == 2) and res[0].is_striped()          # predicates answer at once
+        del res[5], res[17]                                       # freed while pending: withdrawn
+        keep = [k for k in range(300) if k not in (5, 18)]
+        got = [(r.get_score(), r.get_end_query(), r.get_end_ref()) for r in res]
+        assert "pmx_" in pkg.lib.pmx_last_kernel().decode()
+        assert got == [want[mode][k] for k in keep], mode
+    # interleaved configurations: each change runs the queue so far
+    mixed = []
+    for k in range(60):
+        mixed.append((k % 3, builders[k % 3].align(qs[k], rs[k])))
+        if k % 7 == 0:
+            mixed.append(("st", bs.align(qs[k], rs[k])))
+    for (tag, r), k in zip(mixed, [x for k in range(60) for x in ([k, k] if k % 7 == 0 else [k])]):
+        if tag == "st":
+            assert (r.get_score(), r.get_matches(), r.get_similar(), r.get_length()) == want_st[k], k
+        else:
+            assert (r.get_score(), r.get_end_query(), r.get_end_ref()) == want[tag][k], (tag, k)
+    # pending results read by another thread
+    res = [builders[2].align(q, s) for q, s in zip(qs[:40], rs[:40])]
+    box = []
+    t = threading.Thread(target=lambda: box.append([r.get_score() for r in res]))
+    t.start(); t.join()
+    assert box[0] == [w[0] for w in want[2][:40]]
+    # the profile arm, and an explicit flush
+    prof = pkg.Profile.new(qs[0], False, pm)
+    alp = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).local().profile(prof).build()
+    res = [alp.align(None, s) for s in rs[:30]]
+    pkg.lib.pmx_flush_deferred()
+    qb, qo = orc.pack([qs[0]] * 30); rb, ro = orc.pack(rs[:30])
+    w = orc.align_batch(orc.SW, qb, qo, rb, ro, 5, 2, om)
+    assert [r.get_score() for r in res] == list(w[:, 0])
+    # a long pair is not deferred (it fills the chip on its own)
+    lq = random_seqs(rng, 1, 3000, 3000)[0]; lr = mutate(rng, lq, 0.1, 0.03)
+    one = builders[2].align(lq, lr)
+    assert "long32" in pkg.lib.pmx_last_kernel().decode()
+    qb, qo = orc.pack([lq]); rb, ro = orc.pack([lr])
+    assert one.get_score() == orc.align_batch(orc.SW, qb, qo, rb, ro, 5, 2, om)[0, 0]

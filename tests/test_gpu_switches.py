@@ -218,6 +218,6 @@ def test_every_switch_is_result_neutral(pkg, orc, monkeypatch):
         inert.append(env) if not changed else None
     # a switch that reroutes nothing here would be tested in name only (chunk sizes and variant caps change no kernel name)
     same_name = set(VALUES) | {"PMX_CIGAR_NO_OVERLAP", "PMX_STATS_NO_OVERLAP", "PMX_TRACE_NO_BFI", "PMX_TRACE_FETCH",      # another instance / schedule of one kernel
-                               "PMX_BSTRIP_TIES_INLINE", "PMX_BSTRIP_CELL_GUARDS",
+                               "PMX_BSTRIP_TIES_INLINE", "PMX_BSTRIP_CELL_GUARDS", "PMX_DEFER_ALIGN",
                                "PMX_NO_FAST_TABLE", "PMX_GENERAL_ONE_WAVE", "PMX_NWSGQ_ENDS_ALWAYS", "PMX_STATS_EQUAL_CHUNKS", "PMX_STATS_NO_SHORT_TAIL"}                       # (single calls do not record a name)
     assert all(any(k in same_name for k in env) for env in inert), inert
