@@ -596,7 +596,8 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
 
 // One device block + one pinned host block per thread for the one-pair entry: a single H2D, the
 // kernel(s), a single D2H.  (The reference's call is a CPU function of ~20 us; no allocation per call.)
-struct SingleWs { void *dev = nullptr; void *pin = nullptr; size_t cap = 0; int device = -1; void *big = nullptr; size_t bigcap = 0; int bigdev = -1; };
+struct SingleWs { void *dev = nullptr; void *pin = nullptr; size_t cap = 0; int device = -1; void *big = nullptr; size_t bigcap = 0; int bigdev = -1;
+                  hipStream_t stream = nullptr; int streamdev = -1; };      // (a stream per host thread: one-pair calls of several threads overlap on the chip)
 static thread_local SingleWs g_single;
 // one device block per host thread for the one-pair calls that return tables (carved up per call: a dozen hipMalloc / hipFree
 // per call cost more than the kernel)
@@ -623,6 +624,13 @@ static void single_big_trim()
 static void single_reserve(size_t bytes)
 {
     int dev = 0; HIP_OR_DIE(hipGetDevice(&dev));
+    if (g_single.streamdev != dev) {
+        // the reference's parallel story is threads calling align() side by side (tests/test_parasail.rs:689-723): on the legacy default
+        // stream their launches would run one after the other (20 k pairs/s whatever the thread count, profiles/r04/thread_table.txt)
+        if (g_single.stream) (void)hipStreamDestroy(g_single.stream);
+        HIP_OR_DIE(hipStreamCreateWithFlags(&g_single.stream, hipStreamNonBlocking));
+        g_single.streamdev = dev;
+    }
     if (g_single.device == dev && g_single.cap >= bytes) return;
     if (g_single.dev) { (void)hipFree(g_single.dev); (void)hipHostFree(g_single.pin); }
     const size_t cap = bytes < 65536 ? 65536 : bytes * 2;
@@ -769,17 +777,17 @@ static parasail_result_t *run_single(const RunSpec &sp, const char *s1, int s1Le
         // the device's address space), so the call is one launch and one wait -- no copy commands in front of and behind it.
         const bool zero_copy = in_bytes <= 4096;
         if (zero_copy) d = h;
-        else HIP_OR_DIE(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, nullptr));
+        else HIP_OR_DIE(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, g_single.stream));
         pmx_config_t cfg; memset(&cfg, 0, sizeof cfg);
         cfg.mode = sp.mode; cfg.sg_flags = sp.sg_flags; cfg.open = open; cfg.extend = gap; cfg.width = sp.width;
         cfg.want = sp.stats ? PMX_WANT_STATS : 0; cfg.matrix = matrix;
         pmx_record_t *drec = (pmx_record_t *)(d + in_bytes);
         pmx_stats_t *dst = (pmx_stats_t *)(d + in_bytes + 16);
         const int64_t *doff = (const int64_t *)(d + qpad + rpad);
-        if (run_batch_device(&cfg, 1, d, doff, 0, d + qpad, doff + 2, s1Len, s2Len, drec, sp.stats ? dst : nullptr, nullptr))
+        if (run_batch_device(&cfg, 1, d, doff, 0, d + qpad, doff + 2, s1Len, s2Len, drec, sp.stats ? dst : nullptr, g_single.stream))
             die(g_err, hipSuccess);
-        if (!zero_copy) HIP_OR_DIE(hipMemcpyAsync(h + in_bytes, d + in_bytes, 32, hipMemcpyDeviceToHost, nullptr));
-        HIP_OR_DIE(hipStreamSynchronize(nullptr));
+        if (!zero_copy) HIP_OR_DIE(hipMemcpyAsync(h + in_bytes, d + in_bytes, 32, hipMemcpyDeviceToHost, g_single.stream));
+        HIP_OR_DIE(hipStreamSynchronize(g_single.stream));
         pmx_record_t rec; pmx_stats_t st;
         memcpy(&rec, h + in_bytes, sizeof rec); memcpy(&st, h + in_bytes + 16, sizeof st);
         res->score = rec.score; res->end_query = rec.end_query; res->end_ref = rec.end_ref;

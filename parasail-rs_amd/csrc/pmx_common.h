@@ -49,7 +49,7 @@ int pmx_launch_sw16_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m,
                           pmx_record_t *d_out, uint32_t *tbuf, int Tmax, hipStream_t stream);
 
 // Bias of the second-generation nw/sg arithmetic (0: its exact window does not hold for this batch).
-int pmx_nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, int rowx = 0);
+int pmx_nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, int rowx = 0, int shape_rows = 0 /* > 0: the rows of the shape that will run */);
 // Packed statistics kernel (pmx_stats16p.hip): 0 launched, 1 not eligible, <0 HIP error.
 int pmx_launch_stats16p(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext,
                         pmx_record_t *d_out, pmx_stats_t *d_stats, hipStream_t stream, const char **kernel_name);

@@ -1640,6 +1640,8 @@ template <int G, int R, bool TR = false, bool FETCH = false, bool TRB = false>
 static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int nb,
                         pmx_record_t *d_out, hipStream_t stream, uint32_t *tbuf = nullptr, int Tmax = 0)
 {
+    // the window proof once more with THIS shape's rows (round-3 advice: the estimate inside pmx_nwsgv_bias can be smaller than G * R)
+    if (!b.track8 && !pmx_nwsgv_bias(b, m, open, ext, 1, G * R)) return 1;
     if (TR && !TRB && (m.max > 0 ? m.max : 0) + 2 * open <= 250 && !pmx_env("PMX_TRACE_NO_BFI"))     // bounded differences: the one-instruction merge
         return launch_nwsgv<G, R, TR, FETCH, TR>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     constexpr int RS = (R + 3) / 4 * 4, NP = 2 * (64 / G);
@@ -1665,6 +1667,7 @@ static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
                 const int nb_rowx = pmx_nwsgv_bias(b, m, open, ext, 1);      // (the caller's nb is the tracking form's: no row offset)
                 if (nb_rowx && m.msize <= 5 && b.blockflag && !b.q_shared && (col_pen || row_pen) && !pmx_env("PMX_NWSG16_NO_PERMTABLE")) {
                     const size_t lds_pt = (size_t)NP * RP + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40 + 160 + (size_t)NP * ((G * R + 3) / 4 * 4) + 32;
+                  if (lds_pt <= 160 * 1024 && (lds_pt <= 48 * 1024 || pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R, TR, false, TRB, true>)) == 0)) {
                     hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, false, TRB, true>), dim3((unsigned)blocks), dim3(64), lds_pt, stream,
                                        b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
                                        m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb_rowx, b.perm, d_out, tbuf, Tmax,
@@ -1673,6 +1676,7 @@ static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
                     if (e != hipSuccess) return -(int)e;
                     only8 = b.blockflag;
                     g_nwsgv_pt = true;
+                  }       // (else: the staged references do not fit beside the tables -- the LDS-profile form takes every block)
                 }
             }
             { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R, TR, FETCH, TRB, false, false>)); if (rc) return rc; }
@@ -1694,14 +1698,18 @@ static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
         if (m.msize <= 5 && b.blockflag && !b.track8 && !b.q_shared && !pmx_env("PMX_NWSG16_NO_PERMTABLE")) {
             const size_t lds_pt = (size_t)NP * RP + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)NP * 40 + 160 + (size_t)NP * ((G * R + 3) / 4 * 4) + 32 +
                                   (TR ? (size_t)64 * 33 * 4 : 0);
-            hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, false, TRB, true>), dim3((unsigned)blocks), dim3(64), lds_pt, stream,
-                               b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
-                               m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax,
-                               0, b.blockflag, (const int *)nullptr);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return -(int)e;
-            only = b.blockflag;
-            g_nwsgv_pt = true;
+            // (more than the default 48 KB of dynamic LDS -- short queries against references of several kbp -- needs the opt-in; where the
+            //  staged references do not fit at all, or the opt-in fails, the LDS-profile form below takes every block)
+            if (lds_pt <= 160 * 1024 && (lds_pt <= 48 * 1024 || pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16v_kernel<G, R, TR, false, TRB, true>)) == 0)) {
+                hipLaunchKernelGGL((pmx_nwsg16v_kernel<G, R, TR, false, TRB, true>), dim3((unsigned)blocks), dim3(64), lds_pt, stream,
+                                   b.qbuf, b.qoff, b.rbuf, b.roff, (long long)b.n, m.scores, m.mapper,
+                                   m.msize, open, ext, RP, b.q_shared, col_pen, row_pen, s1_end ? 1 : 0, s2_end ? 1 : 0, nb, b.perm, d_out, tbuf, Tmax,
+                                   0, b.blockflag, (const int *)nullptr);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return -(int)e;
+                only = b.blockflag;
+                g_nwsgv_pt = true;
+            }
         }
     }
     if (!only && b.blockflag) {                             // every block bottom-aligned: the walk reads the flags
@@ -1718,14 +1726,17 @@ static int launch_nwsgv(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
 
 // Second-generation eligibility: the profile byte score + open must fit, and the proven value range plus
 // the skew growth must fit the exact window with the bias chosen here.  Returns the bias, or 0.
-int pmx_nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, int rowx)
+int pmx_nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, int rowx, int shape_rows)
 {
     if (pmx_env("PMX_NWSG16_GEN1")) return 0;
     if (m.msize > PMX_MAX_FAST_MSIZE - 1 || open < ext || ext < 0 || b.max_rlen > 30000) return 0;
     const long long hi = (long long)(b.max_qlen < b.max_rlen ? b.max_qlen : b.max_rlen) * (m.max > 0 ? m.max : 0) + (m.max > 0 ? m.max : 0);
     long long lo, growth;
     // rows of the shape that will hold the query: at most twice the query's (+ the smallest shapes' 160 / 192), at most 2 048
-    const long long rows = 2 * b.max_qlen + 64 < 192 ? 192 : 2 * b.max_qlen + 64 < 2048 ? 2 * b.max_qlen + 64 : 2048;
+    // (shape_rows > 0: the launcher's re-check with the G * R of the shape it really picked -- short queries against long references can
+    //  land on a larger shape than this estimate, and the kernels' own row offsets and capture bias use the real one)
+    const long long rows = shape_rows > 0 ? shape_rows
+                         : 2 * b.max_qlen + 64 < 192 ? 192 : 2 * b.max_qlen + 64 < 2048 ? 2 * b.max_qlen + 64 : 2048;
     if (rowx) {
         // Row offset + column skew: a value of cell (i, j) is stored + (i + j) ext, and H(i, j) >= -(2 open + (i + j) ext) always (a
         // gap along row -1, then one down column j): what is stored never falls more than 2 open (+ the one step of E / F / H - C /
