@@ -13,7 +13,7 @@ ONLY=${2:-2345tl}
 R=/root/repo
 mkdir -p $R/profiles/$TAG $R/gpurun_out
 export PYTHONUNBUFFERED=1
-for spec in "2|pmx_sw16_kernel<8, 19, 6>|" "3|pmx_nwsg16q_kernel|pmx_walkp_kernel" "4|pmx_nwsg16v_kernel|pmx_walkp_kernel" "5|pmx_sw16_kernel<64, 16, 6>|pmx_banded"; do
+for spec in "2|pmx_sw16_kernel<8, 19, 6>|" "3|pmx_nwsg16q_kernel|pmx_walkp_kernel" "4|pmx_nwsg16v_kernel|pmx_walkp_kernel" "5|pmx_sw16_kernel<64, 16, 6>|pmx_bstrip_kernel<8, 13, 3"; do
     CFG=${spec%%|*}; REST=${spec#*|}; NEEDLE=${REST%%|*}; NEEDLE2=${REST#*|}
     case "$ONLY" in *"$CFG"*) ;; *) continue ;; esac
     # (a) the serialised pipeline under rocprofv3: kernel trace, then the PMC passes; the traced run's own bench line is kept
@@ -22,7 +22,10 @@ for spec in "2|pmx_sw16_kernel<8, 19, 6>|" "3|pmx_nwsg16q_kernel|pmx_walkp_kerne
     OUT=$R/gpurun_out/prof_${TAG}_cfg$CFG
     cp $OUT/cfg${CFG}_pmc_summary.json $OUT/cfg${CFG}_kernel_stats.csv $R/profiles/$TAG/ 2>/dev/null
     grep -h '^{"metric"' $OUT/trace.log | tail -1 > $R/profiles/$TAG/bench_cfg${CFG}_traced_run.json
-    if [ -n "$NEEDLE2" ]; then python3 $R/profiles/summarize_pmc.py $OUT "$NEEDLE2" $R/profiles/$TAG/cfg${CFG}_${NEEDLE2#pmx_}_pmc_summary.json 6; fi
+    if [ -n "$NEEDLE2" ]; then
+        NAME2=$(echo "${NEEDLE2#pmx_}" | sed 's/_kernel.*//')       # (a needle may carry template arguments: "pmx_bstrip_kernel<8, 13, 3")
+        python3 $R/profiles/summarize_pmc.py $OUT "$NEEDLE2" "$R/profiles/$TAG/cfg${CFG}_${NAME2}_pmc_summary.json" 6
+    fi
     # (b) the bench lines (they quote the counters just collected): serialised, then as shipped
     if [ "$CFG" = "3" ] || [ "$CFG" = "4" ]; then
         python3 $R/bench.py --config $CFG --no-cpu-baseline > $R/profiles/$TAG/bench_cfg${CFG}_serial.json 2>> $R/gpurun_out/bench_${TAG}_cfg$CFG.err || exit 1
