@@ -34,7 +34,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     [b.global_, b.semi_global, b.local][mode]()
     sg = orc.SG_ALL
     if mode == 1:
-        sg = int(rng.integers(0, 16))
+        sg = int(rng.integers(1, 16))
         qg = [t for f, t in ((orc.S1_BEG, "prefix"), (orc.S1_END, "suffix")) if sg & f]
         dg = [t for f, t in ((orc.S2_BEG, "prefix"), (orc.S2_END, "suffix")) if sg & f]
         b.allow_query_gaps(qg).allow_ref_gaps(dg)
