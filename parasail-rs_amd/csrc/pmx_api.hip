@@ -1559,6 +1559,8 @@ static int long_batch(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch 
     // R = 4 (256-row bands) also for batches that fill the chip: 1 024-row bands (R = 16) share a step's fixed work among four
     // times the rows, but the longer dependent chain per step costs more (512 x 5 kbp^2: 5.0 ms against 6.5 ms, measured)
     int R = 4; long long bstride = 0; int nbmax = 0;
+    // a single pair (or a handful) cannot fill the chip with 256-row bands: 128-row bands are twice the waves, each with a shorter step
+    if (const char *e = pmx_env("PMX_LONG_ROWS_PER_LANE")) R = atoi(e) == 2 ? 2 : atoi(e) == 16 ? 16 : 4;
     size_t per_pair = pmx_long_scratch_bytes(1, max_qlen, max_rlen, R, &bstride, &nbmax);
     if (per_pair > ((size_t)4 << 30)) { R = 16; per_pair = pmx_long_scratch_bytes(1, max_qlen, max_rlen, R, &bstride, &nbmax); }
     size_t fb = 0, tb = 0;
@@ -1594,7 +1596,7 @@ static int long_batch(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch 
                 "the call was redone on the per-pair kernels");
         return 1;
     }
-    g_last_kernel = R == 4 ? "pmx_long32_kernel<4>/bands across the chip" : "pmx_long32_kernel<16>/bands across the chip";
+    g_last_kernel = R == 2 ? "pmx_long32_kernel<2>/bands across the chip" : R == 4 ? "pmx_long32_kernel<4>/bands across the chip" : "pmx_long32_kernel<16>/bands across the chip";
     return 0;
 }
 

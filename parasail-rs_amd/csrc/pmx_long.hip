@@ -18,8 +18,9 @@
 // depends on finished bands only -- also when two such grids share the chip (two host threads, each with its own scratch and
 // stream: tests/test_gpu_long.py runs that).  The wait is therefore BOUNDED: a band that polls `spin_limit` times (seconds; a
 // legitimate wait is the producer's next 64 columns, microseconds), or sees the launch's abort word set, sets the word and
-// leaves; every band downstream finds the word (or runs into the limit itself) and leaves too, the finalize kernel marks the
-// launch's records, and the host (`long_batch`) redoes the call on the per-pair kernels and says so in pmx_last_error().
+// stops waiting for good (it finishes its sweep on whatever the buffer holds); every band downstream finds the word (or runs
+// into the limit itself) and does the same, the finalize kernel marks the launch's records, and the host (`long_batch`) redoes
+// the call on the per-pair kernels and says so in pmx_last_error().
 // Reference symbols take the same road: 64 mapped symbols per lane-parallel load, rotated to lane 0 and handed down the lanes
 // with the wave -- no reference in LDS, no length limit.  The LDS holds the band's query profile only (int16 [symbol][row]).
 //
@@ -108,6 +109,8 @@ void pmx_long32_kernel(PmxLongArgs a)
     int symch = 0, Hb = 0, Fb = 0, symcur = msize * (BR * 2);
     int nraw = 0; unsigned long long ngran = 0;
     bool dead = false;                                 // wave-uniform: this band gave up waiting (or found the abort word)
+    const int spin_limit = a.spin_limit;
+    int *const abort_word = a.abort_word;
     auto prefetch_sym = [&](int base) { const int c = base + lane; nraw = c < rl ? (int)r[c] : -1; };
     auto prefetch_bound = [&](int base) { if (bin) ngran = __hip_atomic_load(bin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     // symbols of columns [base, base + 64) take over the rotating register (one step BEFORE the first of them is worked on:
@@ -118,16 +121,20 @@ void pmx_long32_kernel(PmxLongArgs a)
     };
     auto reload_bound = [&](int base) {
         if (bin && base < RU) {                            // (the chunk behind the reference is padding on both sides: never written, never needed)
-            int spins = 0;
-            while (__builtin_amdgcn_ballot_w64(ngran == LONG_SENT) != 0) {          // the producer is not that far yet
-                if (spins >= a.spin_limit || ((spins & 63) == 63 && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    if (lane == 0) __hip_atomic_store(a.abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    dead = true;
-                    return;
+            // The tight poll is what every band's pipeline lag is made of; the limit and the abort word are looked at once per 64 polls.
+            // A band that gives up does NOT leave (an exit in the middle of the sweep cost global alignment 70 % -- 4.2 -> 7.1 ms at
+            // 20 kbp -- whatever the poll looked like): it stops waiting and finishes its sweep on whatever the buffer holds, as does
+            // every band that finds the abort word; nothing of the launch counts then (finalize), and nothing waits any more.
+            for (int spins = 0; !dead && __builtin_amdgcn_ballot_w64(ngran == LONG_SENT) != 0; spins += 64) {
+                for (int k = 0; k < 64 && __builtin_amdgcn_ballot_w64(ngran == LONG_SENT) != 0; ++k) {      // the producer is not that far yet
+                    __builtin_amdgcn_s_sleep(8);
+                    ngran = __hip_atomic_load(bin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                ++spins;
-                __builtin_amdgcn_s_sleep(8);
-                ngran = __hip_atomic_load(bin + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_ballot_w64(ngran == LONG_SENT) == 0) break;
+                if (spins >= spin_limit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (lane == 0) __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dead = true;
+                }
             }
             Hb = (int)(unsigned)(ngran & 0xFFFFFFFFu); Fb = (int)(unsigned)(ngran >> 32);
         } else if (bin) {
@@ -144,7 +151,8 @@ void pmx_long32_kernel(PmxLongArgs a)
         const int sy = dpp_wave_shr(symch, symcur);
         symch = dpp_wave_shl(symch);
         symcur = sy;
-        if (R == 4) { const int2 v = *reinterpret_cast<const int2 *>(prof_lane + sy); w[0] = v.x; w[1] = v.y; }
+        if (R == 2) w[0] = *reinterpret_cast<const int *>(prof_lane + sy);
+        else if (R == 4) { const int2 v = *reinterpret_cast<const int2 *>(prof_lane + sy); w[0] = v.x; w[1] = v.y; }
         else {
 #pragma unroll
             for (int x = 0; x < R / 8; ++x) {
@@ -211,7 +219,6 @@ void pmx_long32_kernel(PmxLongArgs a)
     advance(w0);
     for (int base = 0; base < T; base += 64) {
         reload_bound(base);
-        if (dead) return;                                  // (nothing downstream is fed any more: those bands leave the same way)
         if (base >= 64 && base < tB) {
             for (int t = base; t < base + 64; t += 2) {
                 step(HA, HB, w0, w1, t, std::false_type());
@@ -344,7 +351,9 @@ int pmx_launch_long(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_f
 #define LONG_LAUNCH(RR, MM) do { \
         const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_long32_kernel<RR, MM>)); if (rc) return rc; \
         hipLaunchKernelGGL((pmx_long32_kernel<RR, MM>), dim3((unsigned)blocks), dim3(64), lds, stream, a); } while (0)
-    if (R == 4) {
+    if (R == 2) {
+        if (mode == PMX_MODE_SW) LONG_LAUNCH(2, PMX_MODE_SW); else if (mode == PMX_MODE_SG) LONG_LAUNCH(2, PMX_MODE_SG); else LONG_LAUNCH(2, PMX_MODE_NW);
+    } else if (R == 4) {
         if (mode == PMX_MODE_SW) LONG_LAUNCH(4, PMX_MODE_SW); else if (mode == PMX_MODE_SG) LONG_LAUNCH(4, PMX_MODE_SG); else LONG_LAUNCH(4, PMX_MODE_NW);
     } else if (R == 16) {
         if (mode == PMX_MODE_SW) LONG_LAUNCH(16, PMX_MODE_SW); else if (mode == PMX_MODE_SG) LONG_LAUNCH(16, PMX_MODE_SG); else LONG_LAUNCH(16, PMX_MODE_NW);

@@ -61,6 +61,7 @@ struct PmxSwitchDoc { const char *name, *kind, *what; };
     X("PMX_GENERAL_ONE_WAVE",         "force", "general kernel: one wave per pair also for few long pairs (no pipelined sharing of a pair among the waves of a workgroup)") \
     X("PMX_GENERAL_CHUNK_BYTES",      "value", "batches through the general kernel (score fallback, score tables): bytes of boundary scratch per chunk (tests force one-pair chunks)") \
     X("PMX_NO_LONG_KERNEL",           "force", "few long pairs: the per-pair kernels instead of the kernel that spreads one pair's query bands over the chip") \
+    X("PMX_LONG_ROWS_PER_LANE",       "value", "long-pair kernel: rows per lane (2, 4 or 16: bands of 128, 256 or 1 024 query rows)") \
     X("PMX_LONG_SPIN_LIMIT",          "value", "long-pair kernel: polls a band waits for the band above before the launch gives up and the call is redone on the per-pair kernels (0: any wait gives up)") \
     X("PMX_LONG_CHUNK_BYTES",         "value", "long-pair kernel over a batch: bytes of boundary scratch per chunk (tests force several chunks)") \
     X("PMX_NO_FAST_TABLE",            "force", "score tables: general kernel instead of the table kernel") \

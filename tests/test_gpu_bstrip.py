@@ -127,3 +127,41 @@ def test_banded_nw_single_pair_entry(pkg, orc):
             res = al.banded_nw(q, r)
             assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_bstrip_kernel/")
             assert (res.get_score(), res.get_end_query(), res.get_end_ref()) == tuple(want)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_one_shared_query_every_mode(pkg, orc, mode):
+    """the profile arm (one shared query, staged once per wave): band centres that enter the matrix deep in the query or miss it,
+    references much shorter and much longer than the query, bands 5 / 31 / 48"""
+    rng = np.random.default_rng(9850 + mode)
+    pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
+    q = random_seqs(rng, 1, 420, 420)[0]
+    rs, dg = [], []
+    for t in range(900):
+        kind = t % 6
+        if kind == 0:
+            a = int(rng.integers(0, 300)); body = mutate(rng, q[a:a + int(rng.integers(20, 420 - a + 1))], 0.08, 0.04)
+            pre = random_seqs(rng, 1, 0, 200)[0]; r = pre + body + random_seqs(rng, 1, 0, 100)[0]; d = len(pre) - a + int(rng.integers(-3, 4))
+        elif kind == 1:
+            r = random_seqs(rng, 1, 1, 60)[0]; d = -int(rng.integers(0, 420))
+        elif kind == 2:
+            r = random_seqs(rng, 1, 300, 900)[0]; d = int(rng.integers(0, len(r)))
+        elif kind == 3:
+            r = random_seqs(rng, 1, 1, 120)[0]; d = int(rng.integers(-600, 300))
+        elif kind == 4:
+            r = mutate(rng, q, 0.1, 0.05); d = int(rng.integers(-4, 5))
+        else:
+            r = q[int(rng.integers(0, 200)):]; d = -(len(q) - len(r))
+        rs.append(r or b"C"); dg.append(d)
+    dg = np.array(dg, dtype=np.int32)
+    b = pkg.Aligner.new().matrix(pm).gap_open(5).gap_extend(2).profile(pkg.Profile.new(q, False, pm))
+    [b.global_, b.semi_global, b.local][mode]()
+    al = b.build()
+    rb, ro = orc.pack(rs)
+    for k in (5, 31, 48):
+        for d_ in (None, dg):
+            got = al.align_batch_banded([], rs, k, d_)
+            assert pkg.lib.pmx_last_kernel().decode().startswith("pmx_bstrip_kernel/")
+            want = orc.align_banded_batch(mode, None, None, rb, ro, 5, 2, om, k, d_, shared_query=q)
+            bad = np.nonzero((got["score"] != want[:, 0]) | (got["end_query"] != want[:, 1]) | (got["end_ref"] != want[:, 2]) | (got["flags"] != 0))[0]
+            assert len(bad) == 0, (mode, k, d_ is None, bad[:5], got[bad[:3]], want[bad[:3]], [(len(rs[x]), int(dg[x])) for x in bad[:3]])

@@ -21,7 +21,7 @@ PARTNERS = {"PMX_STATS_BY_TRACE_ANY": ["PMX_STATS_BY_TRACE"],
             "PMX_BANDED_NO_ROWPERM": ["PMX_BANDED_NO_STRIP"], "PMX_BANDED_NO_SHARED_ROWS": ["PMX_BANDED_NO_STRIP"]}
 VALUES = {"PMX_SW16_VARIANT": ["0", "1", "2"], "PMX_STATS_CHUNK_BYTES": ["3e6"], "PMX_CIGAR_CHUNK_BYTES": ["3e6"],
           "PMX_GENERAL_CHUNK_BYTES": ["1"], "PMX_LONG_CHUNK_BYTES": ["1e6"],
-          "PMX_BSTRIP_SHAPE": ["8x8", "2x16"], "PMX_LONG_SPIN_LIMIT": ["0"]}                      # (its batches: tests/test_gpu_tables.py)
+          "PMX_BSTRIP_SHAPE": ["8x8", "2x16"], "PMX_LONG_SPIN_LIMIT": ["0"], "PMX_LONG_ROWS_PER_LANE": ["2", "16"]}                      # (its batches: tests/test_gpu_tables.py)
 NOT_A_DISPATCH_CHOICE = {"PMX_MATRIX_DIR", "PMX_TIMING", "PMX_CIGAR_SWAP_ID"}          # a path (tests/test_abi.py) and a diagnostics print
 
 
