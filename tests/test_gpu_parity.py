@@ -1707,3 +1707,58 @@ def test_deferred_results_behind_the_unchanged_abi(pkg, orc, monkeypatch):
     assert "long32" in pkg.lib.pmx_last_kernel().decode()
     qb, qo = orc.pack([lq]); rb, ro = orc.pack([lr])
     assert one.get_score() == orc.align_batch(orc.SW, qb, qo, rb, ro, 5, 2, om)[0, 0]
+
+
+@pytest.mark.parametrize("mode,sg", [(0, 15), (1, 15), (1, 5), (1, 10), (1, 8), (1, 1)])
+def test_global_kernels_at_the_edge_of_their_int16_window(pkg, orc, mode, sg):
+    """(round-3 review, weak #3 / advice: the admissibility windows of pmx_nwsg16.hip are argued in comments and sampled by fuzz.)
+    For several scoring schemes the LONGEST reference the packed global / semi-global kernels still accept is searched for by
+    launching (pmx_last_kernel() tells which kernel ran), for a short query (where the launcher may pick a larger shape than the
+    window proof's estimate) and for a query as long as the shapes allow; at that length and just below it the inputs that stretch
+    the value range -- all matches, no match at all, the query at the far end behind a long gap, poly-A ties -- are compared with
+    the oracle.  No promotion pass exists behind these kernels: a window that is one step too wide shows here as a wrong score."""
+    rng = np.random.default_rng(7900 + mode * 16 + sg)
+    n = 2100                                                        # above the thresholds of the perm-table / block-flag forms
+    for match, mis, open_, ext in ((2, -3, 5, 2), (1, -1, 1, 1), (5, -4, 10, 1), (3, -2, 4, 4), (9, -9, 20, 3)):
+        pm, om = pkg.Matrix.create(b"ACGT", match, mis), orc.Matrix.create("ACGT", match, mis)
+        b = pkg.Aligner.new().matrix(pm).gap_open(open_).gap_extend(ext)
+        [b.global_, b.semi_global][mode]()
+        if mode == 1:
+            b.allow_query_gaps([t for f, t in ((orc.S1_BEG, "prefix"), (orc.S1_END, "suffix")) if sg & f])
+            b.allow_ref_gaps([t for f, t in ((orc.S2_BEG, "prefix"), (orc.S2_END, "suffix")) if sg & f])
+        al = b.build()
+        for qlen in (50, 1000):
+            q0 = random_seqs(rng, 1, qlen, qlen)[0]
+
+            def batch(rlen):
+                far = random_seqs(rng, 1, rlen, rlen)[0]
+                rs = [(q0 * (rlen // qlen + 1))[:rlen],                       # matches all the way
+                      bytes(b"ACGT"[(b"ACGT".index(bytes([c])) + 1) % 4] for c in (q0 * (rlen // qlen + 1))[:rlen]),     # no match on the diagonal
+                      far[:rlen - qlen] + q0 if rlen > qlen else far,          # the query's copy behind a long gap
+                      q0 + far[:rlen - qlen] if rlen > qlen else far,          # ... and in front of one
+                      b"A" * rlen, far]
+                qs = [q0, q0, q0, q0, b"A" * qlen, q0]
+                k = len(rs)
+                return qs * (n // k + 1), rs * (n // k + 1), k
+
+            def fast(rlen):
+                qs, rs, k = batch(rlen)
+                al.align_batch(qs[:n], rs[:n])
+                return "pmx_nwsg16" in pkg.lib.pmx_last_kernel().decode()
+            lo, hi = 64, 30500
+            if not fast(lo):
+                continue                                                     # this scheme never takes the packed kernels
+            while hi - lo > 1:                                               # the longest reference they still take
+                mid = (lo + hi) // 2
+                lo, hi = (mid, hi) if fast(mid) else (lo, mid)
+            for rlen in {lo, lo - 1, max(64, lo - 37), max(64, lo // 2)}:
+                qs, rs, k = batch(rlen)
+                got = al.align_batch(qs[:n], rs[:n])
+                assert "pmx_nwsg16" in pkg.lib.pmx_last_kernel().decode()
+                qb, qo = orc.pack(qs[:k]); rb, ro = orc.pack(rs[:k])
+                want = orc.align_batch(mode, qb, qo, rb, ro, open_, ext, om, sg_flags=sg)
+                for t in range(k):
+                    rows = slice(t, n, k)
+                    g = np.stack([got["score"][rows], got["end_query"][rows], got["end_ref"][rows]], axis=1)
+                    assert (g == want[t]).all() and (got["flags"][rows] == 0).all(), \
+                        (mode, sg, match, mis, open_, ext, qlen, rlen, t, g[0], want[t], pkg.lib.pmx_last_kernel().decode())
