@@ -1559,10 +1559,26 @@ static int long_batch(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch 
     // R = 4 (256-row bands) also for batches that fill the chip: 1 024-row bands (R = 16) share a step's fixed work among four
     // times the rows, but the longer dependent chain per step costs more (512 x 5 kbp^2: 5.0 ms against 6.5 ms, measured)
     int R = 4; long long bstride = 0; int nbmax = 0;
-    // a single pair (or a handful) cannot fill the chip with 256-row bands: 128-row bands are twice the waves, each with a shorter step
+    // The form with two columns per step (pmx_long32_kernel_c2) has the shorter time per column, the one-column form the shorter
+    // lag from band to band, and 128-row bands (R = 2) halve a step at twice the bands.  One call of a few pairs is a latency
+    // problem: time = columns x (ns per column) + bands x (ns of lag per band), constants measured on MI355X per form
+    // (profiles/r04/long_shapes.txt); a batch that fills the chip keeps the one-column form with 256-row bands (throughput, measured).
+    int two_cols = 0;
+    if (n <= 16) {
+        const bool sw = cfg->mode == PMX_MODE_SW;
+        const double nb4 = (max_qlen + 255) / 256, nb2 = (max_qlen + 127) / 128, cols = max_rlen;
+        const double t1 = cols * (sw ? 144 : 117) + nb4 * (sw ? 23500 : 22400);
+        const double t24 = cols * (sw ? 113 : 100) + nb4 * (sw ? 35600 : 26400);
+        const double t22 = cols * (sw ? 91 : 76) + nb2 * (sw ? 25300 : 19800);
+        if (t22 < 0.95 * t1 && t22 <= t24) { two_cols = 1; R = 2; }          // (within 5 %: the first form)
+        else if (t24 < 0.95 * t1) two_cols = 1;
+    }
+    if (pmx_env("PMX_LONG_TWO_COLUMNS")) two_cols = 1;
+    if (pmx_env("PMX_LONG_ONE_COLUMN")) { two_cols = 0; R = 4; }
     if (const char *e = pmx_env("PMX_LONG_ROWS_PER_LANE")) R = atoi(e) == 2 ? 2 : atoi(e) == 16 ? 16 : 4;
+    if (R == 16) two_cols = 0;
     size_t per_pair = pmx_long_scratch_bytes(1, max_qlen, max_rlen, R, &bstride, &nbmax);
-    if (per_pair > ((size_t)4 << 30)) { R = 16; per_pair = pmx_long_scratch_bytes(1, max_qlen, max_rlen, R, &bstride, &nbmax); }
+    if (per_pair > ((size_t)4 << 30)) { R = 16; two_cols = 0; per_pair = pmx_long_scratch_bytes(1, max_qlen, max_rlen, R, &bstride, &nbmax); }
     size_t fb = 0, tb = 0;
     if (hipMemGetInfo(&fb, &tb) != hipSuccess) fb = 0;
     size_t budget = std::min<size_t>((size_t)4 << 30, fb / 4) + ((size_t)64 << 20);
@@ -1576,6 +1592,8 @@ static int long_batch(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch 
     // the bands of a pair wait for one another across workgroups; the wait is bounded (pmx_long.hip): ~2 us a poll
     int spin_limit = 1 << 20;
     if (const char *e = pmx_env("PMX_LONG_SPIN_LIMIT")) spin_limit = atoi(e);             // tests force the give-up path
+    int chunk_cols = 16;
+    if (const char *e = pmx_env("PMX_LONG_CHUNK_COLS")) chunk_cols = atoi(e) == 64 ? 64 : 16;
     HIP_OR_RET(hipMemsetAsync(scr, 0, 64, st));
     for (int64_t c0 = 0; c0 < n; c0 += chunk) {
         PmxBatch b = b0;
@@ -1583,7 +1601,7 @@ static int long_batch(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch 
         b.n = (n - c0 < chunk) ? n - c0 : chunk;
         if (!b.q_shared) b.qoff = b0.qoff + c0;
         b.roff = b0.roff + c0;
-        const int rc = pmx_launch_long(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, R, scr, d_out + c0, sat_above, force_sat, st, spin_limit);
+        const int rc = pmx_launch_long(b, dm.d, cfg->mode, cfg->sg_flags, cfg->open, cfg->extend, R, scr, d_out + c0, sat_above, force_sat, st, spin_limit, chunk_cols, two_cols);
         if (rc < 0) { set_err("long-pair kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc))); return rc; }
         if (rc) return c0 == 0 ? 1 : (set_err("long-pair kernel refused a later chunk"), -1);
     }
@@ -1596,7 +1614,9 @@ static int long_batch(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch 
                 "the call was redone on the per-pair kernels");
         return 1;
     }
-    g_last_kernel = R == 2 ? "pmx_long32_kernel<2>/bands across the chip" : R == 4 ? "pmx_long32_kernel<4>/bands across the chip" : "pmx_long32_kernel<16>/bands across the chip";
+    g_last_kernel = R == 16 ? "pmx_long32_kernel<16>/bands across the chip"
+                  : two_cols ? (R == 2 ? "pmx_long32_kernel_c2<2>/bands across the chip, two columns per step" : "pmx_long32_kernel_c2<4>/bands across the chip, two columns per step")
+                  : (R == 2 ? "pmx_long32_kernel<2>/bands across the chip" : "pmx_long32_kernel<4>/bands across the chip");
     return 0;
 }
 
@@ -1626,7 +1646,9 @@ static int run_batch_device(const pmx_config_t *cfg, int64_t n,
     }
     // Few long pairs (one align() call on kilobases: src/aligner/mod.rs:397-430 has no length limit), or queries beyond the packed
     // kernels' 2 048 rows in any number: the query's bands spread over the chip (pmx_long.hip).
-    if (want == 0 && ((n <= 16 && max_qlen >= 512 && (long long)max_qlen * max_rlen >= (3LL << 20)) || max_qlen > 2048)) {
+    long long long_min_cells = 250000;                     // (600 x 600: 0.18 ms here, 0.23-0.27 ms in the one-wave packed kernels)
+    if (const char *e = pmx_env("PMX_LONG_MIN_CELLS")) long_min_cells = atoll(e);
+    if (want == 0 && ((n <= 16 && max_qlen >= 512 && (long long)max_qlen * max_rlen >= long_min_cells) || max_qlen > 2048)) {
         const int rc = long_batch(cfg, dm, b, n, max_qlen, max_rlen, d_out, st);
         if (rc <= 0) return rc;
     }

@@ -206,7 +206,9 @@ size_t pmx_long_scratch_bytes(long long n, int max_qlen, int max_rlen, int R, lo
 // The first 64 bytes of `scratch` are the call's abort word: the caller zeroes them before the first launch and reads them after the
 // last (non-zero: a band's bounded wait ran out -- every record of the call is marked PMX_FLAG_RERUN and has to be redone elsewhere).
 int pmx_launch_long(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_flags, int open, int ext, int R,
-                    void *scratch, pmx_record_t *d_out, int sat_above, int force_sat, hipStream_t stream, int spin_limit = 1 << 20);
+                    void *scratch, pmx_record_t *d_out, int sat_above, int force_sat, hipStream_t stream, int spin_limit = 1 << 20,
+                    int chunk_cols = 16 /* boundary columns a band takes over at a time: 16 or 64 (two-column form: steps, 32 or 64) */,
+                    int two_cols = 1 /* rows per lane 2 or 4: the form with two columns per step */);
 
 // Run-time CIGAR letter convention (switch PMX_CIGAR_SWAP_ID, read per call): 1 = exchange I and D in everything handed out.
 int pmx_cigar_swapped();

@@ -62,6 +62,10 @@ struct PmxSwitchDoc { const char *name, *kind, *what; };
     X("PMX_GENERAL_CHUNK_BYTES",      "value", "batches through the general kernel (score fallback, score tables): bytes of boundary scratch per chunk (tests force one-pair chunks)") \
     X("PMX_NO_LONG_KERNEL",           "force", "few long pairs: the per-pair kernels instead of the kernel that spreads one pair's query bands over the chip") \
     X("PMX_LONG_ROWS_PER_LANE",       "value", "long-pair kernel: rows per lane (2, 4 or 16: bands of 128, 256 or 1 024 query rows)") \
+    X("PMX_LONG_TWO_COLUMNS",         "force", "long-pair kernel: two columns per step also where the dispatcher's time model prefers one (batches, square pairs)") \
+    X("PMX_LONG_ONE_COLUMN",          "force", "long-pair kernel: one column per step (the first form) instead of two") \
+    X("PMX_LONG_CHUNK_COLS",          "value", "long-pair kernel: boundary columns a band takes over from the band above at a time (16 or 64)") \
+    X("PMX_LONG_MIN_CELLS",           "value", "cells of the largest pair from which a call of at most 16 pairs (queries of 512 rows or more) takes the long-pair kernel") \
     X("PMX_LONG_SPIN_LIMIT",          "value", "long-pair kernel: polls a band waits for the band above before the launch gives up and the call is redone on the per-pair kernels (0: any wait gives up)") \
     X("PMX_LONG_CHUNK_BYTES",         "value", "long-pair kernel over a batch: bytes of boundary scratch per chunk (tests force several chunks)") \
     X("PMX_NO_FAST_TABLE",            "force", "score tables: general kernel instead of the table kernel") \

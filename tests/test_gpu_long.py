@@ -29,9 +29,21 @@ def _builder(pkg, pm, o, e, mode, width=None):
     return b
 
 
+FORMS = {"dispatch": {}, "two columns": {"PMX_LONG_TWO_COLUMNS": "1"}, "two columns, 128-row bands": {"PMX_LONG_TWO_COLUMNS": "1", "PMX_LONG_ROWS_PER_LANE": "2"},
+         "two columns, 64-step chunks": {"PMX_LONG_TWO_COLUMNS": "1", "PMX_LONG_CHUNK_COLS": "64"}}
+
+
+@pytest.fixture(params=list(FORMS))
+def form(request, monkeypatch):
+    """the kernel form: what the dispatcher's time model picks (one column per step for batches and square pairs), or forced"""
+    for k, v in FORMS[request.param].items():
+        monkeypatch.setenv(k, v)
+    return request.param
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("gaps", [(5, 2), (0, 0), (1, 1), (7, 0)])
-def test_ragged_batches_around_chunk_and_band_edges(pkg, orc, mode, gaps):
+def test_ragged_batches_around_chunk_and_band_edges(pkg, orc, mode, gaps, form):
     rng = np.random.default_rng(9900 + mode * 10 + gaps[0])
     pm, om = pkg.Matrix.create(b"ACGT", 2, -3), orc.Matrix.create("ACGT", 2, -3)
     qlens = [3000, 512, 513, 255, 256, 257, 1, 700, 1024, 1025, 2049, 100, 1279, 1280, 1281, 40]
@@ -55,7 +67,7 @@ def test_ragged_batches_around_chunk_and_band_edges(pkg, orc, mode, gaps):
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
-def test_end_positions_under_ties(pkg, orc, mode):
+def test_end_positions_under_ties(pkg, orc, mode, form):
     """periodic sequences: the maximum occurs in many cells, several of them in different bands and lanes"""
     rng = np.random.default_rng(9950 + mode)
     pm, om = pkg.Matrix.create(b"ACGT", 1, -1), orc.Matrix.create("ACGT", 1, -1)
@@ -200,7 +212,7 @@ def _seeds(default):
 
 
 @pytest.mark.parametrize("seed", _seeds([301, 302, 303]))
-def test_fuzz_band_kernel_shapes_modes_and_scoring(pkg, orc, seed):
+def test_fuzz_band_kernel_shapes_modes_and_scoring(pkg, orc, seed, form):
     """random modes, free-end sets, gap models (open < extend and extend = 0 included), matrices over 2-9 letters, lengths around the
     256-row bands and the 64-column chunks, 1-16 pairs per call: pmx_long32_kernel against the oracle"""
     rng = np.random.default_rng(seed)

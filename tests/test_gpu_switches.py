@@ -21,7 +21,7 @@ PARTNERS = {"PMX_STATS_BY_TRACE_ANY": ["PMX_STATS_BY_TRACE"],
             "PMX_BANDED_NO_ROWPERM": ["PMX_BANDED_NO_STRIP"], "PMX_BANDED_NO_SHARED_ROWS": ["PMX_BANDED_NO_STRIP"]}
 VALUES = {"PMX_SW16_VARIANT": ["0", "1", "2"], "PMX_STATS_CHUNK_BYTES": ["3e6"], "PMX_CIGAR_CHUNK_BYTES": ["3e6"],
           "PMX_GENERAL_CHUNK_BYTES": ["1"], "PMX_LONG_CHUNK_BYTES": ["1e6"],
-          "PMX_BSTRIP_SHAPE": ["8x8", "2x16"], "PMX_LONG_SPIN_LIMIT": ["0"], "PMX_LONG_ROWS_PER_LANE": ["2", "16"]}                      # (its batches: tests/test_gpu_tables.py)
+          "PMX_BSTRIP_SHAPE": ["8x8", "2x16"], "PMX_LONG_SPIN_LIMIT": ["0"], "PMX_LONG_ROWS_PER_LANE": ["2", "16"], "PMX_LONG_CHUNK_COLS": ["64"], "PMX_LONG_MIN_CELLS": ["0", "1000000000000"]}                      # (its batches: tests/test_gpu_tables.py)
 NOT_A_DISPATCH_CHOICE = {"PMX_MATRIX_DIR", "PMX_TIMING", "PMX_CIGAR_SWAP_ID"}          # a path (tests/test_abi.py) and a diagnostics print
 
 
@@ -218,6 +218,6 @@ def test_every_switch_is_result_neutral(pkg, orc, monkeypatch):
         inert.append(env) if not changed else None
     # a switch that reroutes nothing here would be tested in name only (chunk sizes and variant caps change no kernel name)
     same_name = set(VALUES) | {"PMX_CIGAR_NO_OVERLAP", "PMX_STATS_NO_OVERLAP", "PMX_TRACE_NO_BFI", "PMX_TRACE_FETCH",      # another instance / schedule of one kernel
-                               "PMX_BSTRIP_TIES_INLINE", "PMX_BSTRIP_CELL_GUARDS", "PMX_DEFER_ALIGN",
+                               "PMX_BSTRIP_TIES_INLINE", "PMX_BSTRIP_CELL_GUARDS", "PMX_DEFER_ALIGN", "PMX_LONG_TWO_COLUMNS", "PMX_LONG_ONE_COLUMN",
                                "PMX_NO_FAST_TABLE", "PMX_GENERAL_ONE_WAVE", "PMX_NWSGQ_ENDS_ALWAYS", "PMX_STATS_EQUAL_CHUNKS", "PMX_STATS_NO_SHORT_TAIL"}                       # (single calls do not record a name)
     assert all(any(k in same_name for k in env) for env in inert), inert
