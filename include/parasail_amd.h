@@ -389,6 +389,10 @@ int pmx_documented_matrix_names(char *buf, int cap);
 int pmx_bstrip_window(int mode, int max_qlen, int max_rlen, int open, int extend, int score_min, int score_max, int capacity, int rows,
                       int double_skew, int *bias, int *low);
 int pmx_bstrip_shape(int band, int *lanes_per_pair, int *offsets_per_lane);
+/* Test hook of the packed global / semi-global kernels (pmx_nwsg16.hip; model: tests/nwsgv_model.c): the host's range proof --
+ * the bias nb of the stored form when the int16 window holds every pair of up to max_qlen x max_rlen under this scoring in a shape of
+ * shape_rows rows (0: the dispatcher's estimate before a shape is picked), else 0.  rowx: the row-offset form (every width but 8). */
+int pmx_window_nwsgv(int max_qlen, int max_rlen, int msize, int score_min, int score_max, int open, int extend, int rowx, int shape_rows);
 
 #ifdef __cplusplus
 }

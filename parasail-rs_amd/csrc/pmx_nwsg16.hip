@@ -1758,6 +1758,15 @@ int pmx_nwsgv_bias(const PmxBatch &b, const PmxDevMatrix &m, int open, int ext, 
     return (int)(1536 - lo + open);
 }
 
+extern "C" int pmx_window_nwsgv(int max_qlen, int max_rlen, int msize, int score_min, int score_max, int open, int ext, int rowx, int shape_rows)
+{
+    PmxBatch b = {};
+    b.max_qlen = max_qlen; b.max_rlen = max_rlen; b.n = 1;
+    PmxDevMatrix m = {};
+    m.msize = msize; m.min = score_min; m.max = score_max;
+    return pmx_nwsgv_bias(b, m, open, ext, rowx, shape_rows);
+}
+
 // Traceback variant (global / semi-global): shapes with 16 rows per lane.  Trace layout: per block
 // Tmax steps x 64 lanes x 16 bytes.
 int pmx_nwsgv_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
