@@ -1512,7 +1512,7 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
         // The remainder after the whole rounds is less than one round: its waves end the batch with the chip mostly idle, so it runs
         // on the shape with half the rows per lane (<32,10> for <16,20>) -- twice the waves, each half as long (cfg 3: 4.8 -> 2.4 ms of tail)
         int variant_k = variant, Tmax_k = Tmax, G_k = G, R_k = R;
-        if (by_rounds && two && bk.n < chunk && R == 20 && !pmx_env("PMX_STATS_NO_SHORT_TAIL")) {
+        if (by_rounds && two && bk.n < chunk && R >= 19 && !pmx_env("PMX_STATS_NO_SHORT_TAIL")) {
             int v2 = 0, T2 = 0, G2 = 0, R2 = 0; size_t tb2 = 0;
             if (pmx_nwsgq_trace_plan(bk, dm.d, cfg->mode, cfg->open, cfg->extend, &v2, &T2, &tb2, &G2, &R2, 1) == 0 && tb2 <= cbytes) {
                 variant_k = v2; Tmax_k = T2; G_k = G2; R_k = R2;

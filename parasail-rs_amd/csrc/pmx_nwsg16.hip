@@ -934,7 +934,7 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
                         const unsigned *__restrict__ perm,
                         pmx_record_t *__restrict__ out, uint32_t *__restrict__ tbuf = nullptr, int Tmax = 0)
 {
-    static_assert(!TR || R == 10 || R == 16 || R == 20, "trace record layouts");
+    static_assert(!TR || R == 10 || R == 16 || R == 19 || R == 20, "trace record layouts");
     const int s1_end = ENDS ? s1_end_arg : 0, s2_end = ENDS ? s2_end_arg : 0;
     constexpr int TD = (R + 3) / 4;               // dwords per trace record (R / 2 bytes per pair, two pairs)
     constexpr int RS = (R + 3) / 4 * 4;
@@ -1042,7 +1042,7 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
         // for R = 20 did not lower the allocator's register count)
         constexpr int HBLK = R;
         int Tpre[HBLK];
-        int tacc = 0, ty[TR ? R / 2 : 1];
+        int tacc = 0, ty[TR ? (R + 1) / 2 : 1];
         int xcarry = diag0;                                  // previous column's H of the row above the block
 #pragma unroll
         for (int k0 = 0; k0 < R; k0 += HBLK) {
@@ -1081,14 +1081,15 @@ void pmx_nwsg16q_kernel(const uint8_t *__restrict__ qbuf, int qlen,
         }
         }
         if (TR) {
+            if (R & 1) ty[R / 2] = tacc;                   // (odd R: the last row has a byte of its own; its low nibble is never read)
             // record: [A bytes 0 .. R/2-1][B bytes 0 .. R/2-1][pad]; u = [A_y A_y+1 B_y B_y+1] of two row pairs
             const int u01 = __builtin_amdgcn_perm(ty[0], ty[1], 0x03070105), u23 = __builtin_amdgcn_perm(ty[2], ty[3], 0x03070105);
             const int a0 = __builtin_amdgcn_perm(u01, u23, 0x01000504), b0 = __builtin_amdgcn_perm(u01, u23, 0x03020706);
             uint32_t *dst = tstage + (t & (TSTG - 1)) * TD;
-            if (R == 20) {
+            if (R >= 19) {
                 // 10 + 10 bytes: a whole number of dwords (the 12-byte record of R = 10 carries two bytes of padding per 20 cells)
-                const int u45 = __builtin_amdgcn_perm(ty[R == 20 ? 4 : 0], ty[R == 20 ? 5 : 0], 0x03070105), u67 = __builtin_amdgcn_perm(ty[R == 20 ? 6 : 0], ty[R == 20 ? 7 : 0], 0x03070105);
-                const int u89 = __builtin_amdgcn_perm(ty[R == 20 ? 8 : 0], ty[R == 20 ? 9 : 0], 0x03070105);
+                const int u45 = __builtin_amdgcn_perm(ty[R >= 19 ? 4 : 0], ty[R >= 19 ? 5 : 0], 0x03070105), u67 = __builtin_amdgcn_perm(ty[R >= 19 ? 6 : 0], ty[R >= 19 ? 7 : 0], 0x03070105);
+                const int u89 = __builtin_amdgcn_perm(ty[R >= 19 ? 8 : 0], ty[R >= 19 ? 9 : 0], 0x03070105);
                 const int b1 = __builtin_amdgcn_perm(u45, u67, 0x03020706);
                 dst[0] = (uint32_t)a0;                                                    // A0 A1 A2 A3
                 dst[1] = (uint32_t)__builtin_amdgcn_perm(u45, u67, 0x01000504);           // A4 .. A7
@@ -1513,7 +1514,7 @@ static int launch_nwsgq(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
     const int s1_end = sg && (sg_flags & PMX_SG_QE), s2_end = sg && (sg_flags & PMX_SG_DE);
     const long long blocks = (b.n + NP - 1) / NP;
     if (blocks <= 0) return 0;
-    if constexpr (TR && R == 20) {
+    if constexpr (TR && R >= 19) {
         if (!s1_end && !s2_end && !pmx_env("PMX_NWSGQ_ENDS_ALWAYS")) {       // no free end: the instance without captures (three waves per SIMD)
             { const int rc = pmx_ensure_lds_attr(reinterpret_cast<const void *>(&pmx_nwsg16q_kernel<G, R, WAVES, TR, false>)); if (rc) return rc; }
             hipLaunchKernelGGL((pmx_nwsg16q_kernel<G, R, WAVES, TR, false>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream,
@@ -1535,17 +1536,20 @@ static int launch_nwsgq(const PmxBatch &b, const PmxDevMatrix &m, int mode, int 
 // (the walk needs row -1), bounded differences for the one-instruction decision merge.  *variant = 30 + shape index.
 // <16,20>: 320 rows like <32,10>, but twice the rows per lane -- the per-step work that is not per row (hand-off, captures, record
 // assembly, staging flush) is shared by twice the cells -- and a record of exactly 20 bytes instead of 12 for half the cells.
-static const int kQShapeG[6] = {16, 16, 16, 32, 32, 64}, kQShapeR[6] = {10, 16, 20, 10, 16, 16};
+// (<16,19>, round 4: a 300-row query -- the typical protein -- fills 300 of 304 rows instead of 300 of 320; tried before <16,20>)
+static const int kQShapeG[7] = {16, 16, 16, 32, 32, 64, 16}, kQShapeR[7] = {10, 16, 20, 10, 16, 16, 19}, kQShapeOrder[7] = {0, 1, 6, 2, 3, 4, 5};
 int pmx_nwsgq_trace_plan(const PmxBatch &b, const PmxDevMatrix &m, int mode, int open, int ext,
                          int *variant, int *Tmax, size_t *trace_bytes, int *G_out, int *R_out, int short_waves)
 {
     if (mode != PMX_MODE_NW && mode != PMX_MODE_SG) return 1;
     if (!b.q_shared || !pmx_nwsgv_bias(b, m, open, ext, 1)) return 1;
     if ((m.max > 0 ? m.max : 0) + 2 * open > 250) return 1;
-    for (int v = 0; v < 6; ++v) {
+    for (int vo = 0; vo < 7; ++vo) {
+        const int v = kQShapeOrder[vo];
         const int G = kQShapeG[v], R = kQShapeR[v];
         if (b.q_shared > G * R - 1) continue;
-        if (R == 20 && (short_waves || pmx_env("PMX_NWSGQ_NO_R20"))) continue;      // (short_waves: half the rows per lane = half the time per wave)
+        if (R >= 19 && (short_waves || pmx_env("PMX_NWSGQ_NO_R20"))) continue;      // (short_waves: half the rows per lane = half the time per wave)
+        if (R == 19 && pmx_env("PMX_NWSGQ_NO_R19")) continue;
         const size_t lds = (size_t)(m.msize + 1) * G * ((R + 3) / 4 * 4) + 8 + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)(2 * (64 / G) * 4) * 24 +
                            (size_t)4 * 64 * (PMX_QSTAGE * ((R + 3) / 4) + 1) * 4;
         if (lds > 160 * 1024) continue;
@@ -1574,7 +1578,7 @@ static long long nwsgq_round_pairs(size_t lds)
 long long pmx_nwsgq_trace_round_pairs(int variant, const PmxDevMatrix &m, int mode, int sg_flags)
 {
     const int v = variant - 30;
-    if (v < 0 || v >= 6) return 0;
+    if (v < 0 || v >= 7) return 0;
     const int G = kQShapeG[v], R = kQShapeR[v];
     const size_t lds = (size_t)(m.msize + 1) * G * ((R + 3) / 4 * 4) + 8 + (size_t)m.msize * m.msize * 2 + 256 + 8 + (size_t)(2 * (64 / G) * 4) * 24 +
                        (size_t)4 * 64 * (PMX_QSTAGE * ((R + 3) / 4) + 1) * 4;
@@ -1586,6 +1590,7 @@ long long pmx_nwsgq_trace_round_pairs(int variant, const PmxDevMatrix &m, int mo
     case 3: return nwsgq_round_pairs<32, 10, true>(lds);
     case 4: return nwsgq_round_pairs<32, 16, true>(lds);
     case 5: return nwsgq_round_pairs<64, 16, true>(lds);
+    case 6: return (ends || pmx_env("PMX_NWSGQ_ENDS_ALWAYS")) ? nwsgq_round_pairs<16, 19, true>(lds) : nwsgq_round_pairs<16, 19, false>(lds);
     }
     return 0;
 }
@@ -1602,6 +1607,7 @@ int pmx_launch_nwsgq_trace(int variant, const PmxBatch &b, const PmxDevMatrix &m
     case 3: return launch_nwsgq<32, 10, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 4: return launch_nwsgq<32, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     case 5: return launch_nwsgq<64, 16, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
+    case 6: return launch_nwsgq<16, 19, true>(b, m, mode, sg_flags, open, ext, nb, d_out, stream, tbuf, Tmax);
     }
     return 1;
 }

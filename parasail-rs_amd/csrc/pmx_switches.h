@@ -37,6 +37,7 @@ struct PmxSwitchDoc { const char *name, *kind, *what; };
     X("PMX_STATS_BY_TRACE_ANY",       "force", "statistics by traceback also for large alphabets with long references") \
     X("PMX_NO_STATS_BY_TRACE",        "force", "statistics: never by traceback (statistics-carrying kernels)") \
     X("PMX_NWSGQ_ENDS_ALWAYS",        "force", "shared-profile traceback sweep <16,20>, global alignment: the instance with the free-end captures compiled in (two waves per SIMD)") \
+    X("PMX_NWSGQ_NO_R19",             "force", "statistics by traceback, profile arm: the <16,20> shape instead of <16,19> for queries of 256-303 rows") \
     X("PMX_NWSGQ_NO_R20",             "force", "statistics by traceback, profile arm: the <32,10> shape instead of <16,20> for queries of 256-319 rows") \
     X("PMX_STATS_CHUNK_BYTES",        "value", "statistics by traceback: bytes of trace scratch per chunk (tests force several chunks)") \
     X("PMX_STATS_EQUAL_CHUNKS",       "force", "statistics by traceback, shared profile: chunks of equal size instead of whole rounds of resident workgroups") \

@@ -43,9 +43,9 @@ void pmx_walkp_kernel(const uint8_t *__restrict__ qbuf, const int64_t *__restric
                       int32_t *__restrict__ nops, int32_t *__restrict__ beg, int32_t *__restrict__ textlen)
 {
     constexpr int QP = G * R, NPW = 2 * (64 / G);
-    constexpr int RB = R / 2;                          // bytes per pair in a record
+    constexpr int RB = (R + 1) / 2;                    // bytes per pair in a record (odd R: the last row has a byte of its own)
     constexpr int D = (2 * RB + 3) / 4;                // dwords per record
-    static_assert(R % 2 == 0 && D <= 5, "record layout");
+    static_assert(D <= 5, "record layout");
     __shared__ unsigned char s_map[256];
     __shared__ int16_t s_scores[PMX_MAX_FAST_MSIZE * PMX_MAX_FAST_MSIZE];
     for (int x = threadIdx.x; x < 256; x += blockDim.x) s_map[x] = mapper[x];
@@ -233,6 +233,9 @@ int pmx_launch_walkp(int gsel, int R, const PmxBatch &b, const PmxDevMatrix &m, 
     } else if (R == 20) {
         if (gsel != 1) return 1;
         WALKP(16, 20);
+    } else if (R == 19) {
+        if (gsel != 1) return 1;
+        WALKP(16, 19);
     } else if (R == 10) {
         switch (gsel) {
         case 1: WALKP(16, 10); break;
