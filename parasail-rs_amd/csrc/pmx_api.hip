@@ -1409,15 +1409,15 @@ static int general_batch(const pmx_config_t *cfg, const DevMat &dm, int64_t n,
 // tie-breaks as the traceback bits): the shared-profile sweep writes the packed 4-bit records (14.75 instructions per two
 // cells against 34 for the kernel that carries nine statistics planes) and the walk counts along the path.  Chunks bound
 // the trace scratch; the walk of chunk c runs beside the sweep of chunk c + 1 on a second stream.
-struct TraceWs { hipStream_t walk = nullptr, aux = nullptr; hipEvent_t sweep_done[2] = {nullptr, nullptr}, walk_done[2] = {nullptr, nullptr}, start = nullptr; int dev = -1; };
+struct TraceWs { hipStream_t walk = nullptr, aux = nullptr, aux2 = nullptr; hipEvent_t sweep_done[3] = {nullptr, nullptr, nullptr}, walk_done[3] = {nullptr, nullptr, nullptr}, start = nullptr; int dev = -1; };
 static thread_local TraceWs g_tws;
 static int trace_ws_init()
 {
     int dev = 0; HIP_OR_RET(hipGetDevice(&dev));
     if (g_tws.dev == dev) return 0;
     if (g_tws.walk) {                                   // the thread moved to another device: release the old device's objects
-        (void)hipStreamDestroy(g_tws.walk); (void)hipStreamDestroy(g_tws.aux); (void)hipEventDestroy(g_tws.start);
-        for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(g_tws.sweep_done[k]); (void)hipEventDestroy(g_tws.walk_done[k]); }
+        (void)hipStreamDestroy(g_tws.walk); (void)hipStreamDestroy(g_tws.aux); (void)hipStreamDestroy(g_tws.aux2); (void)hipEventDestroy(g_tws.start);
+        for (int k = 0; k < 3; ++k) { (void)hipEventDestroy(g_tws.sweep_done[k]); (void)hipEventDestroy(g_tws.walk_done[k]); }
         g_tws = TraceWs();
     }
     // the walk gets the higher priority: its few, latency-bound workgroups slip in between the sweep's as those retire
@@ -1425,8 +1425,9 @@ static int trace_ws_init()
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     HIP_OR_RET(hipStreamCreateWithPriority(&g_tws.walk, hipStreamNonBlocking, prio_hi));
     HIP_OR_RET(hipStreamCreateWithFlags(&g_tws.aux, hipStreamNonBlocking));
+    HIP_OR_RET(hipStreamCreateWithFlags(&g_tws.aux2, hipStreamNonBlocking));
     HIP_OR_RET(hipEventCreateWithFlags(&g_tws.start, hipEventDisableTiming));
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         HIP_OR_RET(hipEventCreateWithFlags(&g_tws.sweep_done[k], hipEventDisableTiming));
         HIP_OR_RET(hipEventCreateWithFlags(&g_tws.walk_done[k], hipEventDisableTiming));
     }
@@ -1491,30 +1492,42 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
     // (PMX_STATS_NO_OVERLAP: sweep and walk of every chunk back to back on the caller's stream, one trace buffer -- the form the
     //  serialised kernel traces under profiles/ are taken in: per-launch durations of overlapping launches cannot be added up)
     const bool two = chunk < b.n && !pmx_env("PMX_STATS_NO_OVERLAP");
+    // The remainder after the whole rounds (a few long waves that would end the call with the chip nearly idle, after waiting for a trace
+    // buffer to come free: 3.1 ms of a 38 ms cfg-3 step for 1.7 % of the pairs, measured) goes FIRST, on a stream and a trace buffer of
+    // its own, beside the first big chunks.  Not through the host entry: there the last references are the last to arrive.
+    long long rem_n = 0;
+    if (by_rounds && two && !g_upload && b.n % chunk != 0 && !pmx_env("PMX_STATS_TAIL_LAST")) rem_n = b.n % chunk;
+    size_t rbytes = 0;
+    if (rem_n) {
+        PmxBatch br = b; br.n = rem_n;
+        int v_ = 0, T_ = 0, G_ = 0, R_ = 0;
+        (void)pmx_nwsgq_trace_plan(br, dm.d, cfg->mode, cfg->open, cfg->extend, &v_, &T_, &rbytes, &G_, &R_);
+        size_t r2 = 0;
+        if (pmx_nwsgq_trace_plan(br, dm.d, cfg->mode, cfg->open, cfg->extend, &v_, &T_, &r2, &G_, &R_, 1) == 0 && r2 > rbytes) rbytes = r2;
+        rbytes = (rbytes + 255) & ~(size_t)255;
+    }
     uint32_t *tbuf = nullptr;
-    if (scratch_reserve(cbytes * (two ? 2 : 1), (void **)&tbuf, SCR_TRACE)) return -1;
+    if (scratch_reserve(cbytes * (two ? 2 : 1) + rbytes, (void **)&tbuf, SCR_TRACE)) return -1;
     const bool sg = cfg->mode == PMX_MODE_SG;
     const int col_pen = !(sg && (cfg->sg_flags & PMX_SG_QB)), row_pen = !(sg && (cfg->sg_flags & PMX_SG_DB));
     // Sweeps of consecutive chunks go to two streams in turn (the caller's and an internal one): a chunk is a few thousand equally
     // long waves, so the tail of chunk c's launch is backfilled by chunk c + 1's workgroups instead of idling the chip.
     if (two) { HIP_OR_RET(hipEventRecord(g_tws.start, st)); HIP_OR_RET(hipStreamWaitEvent(g_tws.aux, g_tws.start, 0)); }
-    int idx = 0;
-    for (long long c0 = 0; c0 < b.n; c0 += chunk, ++idx) {
+    if (rem_n) HIP_OR_RET(hipStreamWaitEvent(g_tws.aux2, g_tws.start, 0));
+    // one chunk: positions [c0, c0 + n_k) of the batch; sweep on `sws` into `tb`, walk on the walk stream behind it (slot = which events)
+    auto run_chunk = [&](long long c0, long long n_k, uint32_t *tb, size_t tb_bytes, hipStream_t sws, int slot, bool short_waves) -> int {
         PmxBatch bk = b;
-        bk.n = (b.n - c0 < chunk) ? b.n - c0 : chunk;
+        bk.n = n_k;
         pmx_record_t *out_k = d_out; pmx_stats_t *st_k = d_stats;
         if (b.perm) bk.perm = b.perm + c0;                    // positions c0 .. of the processing order; records stay indexed by pair
         else { bk.roff = b.roff + c0; out_k = d_out + c0; st_k = d_stats + c0; }
-        uint32_t *tb = (uint32_t *)((unsigned char *)tbuf + (two ? (size_t)(idx & 1) * cbytes : 0));
-        const hipStream_t sws = (two && (idx & 1)) ? g_tws.aux : st;
-        if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(sws, g_tws.walk_done[idx & 1], 0));    // this buffer's previous walk is done
         if (!b.perm && upload_wait(c0 + bk.n, sws, sws == st ? 0 : 1)) return -1;                  // (host entry: this chunk's references are up)
-        // The remainder after the whole rounds is less than one round: its waves end the batch with the chip mostly idle, so it runs
-        // on the shape with half the rows per lane (<32,10> for <16,20>) -- twice the waves, each half as long (cfg 3: 4.8 -> 2.4 ms of tail)
+        // The remainder after the whole rounds is less than one round: it runs on the shape with half the rows per lane (<32,10> for
+        // <16,20> / <16,19>) -- twice the waves, each half as long
         int variant_k = variant, Tmax_k = Tmax, G_k = G, R_k = R;
-        if (by_rounds && two && bk.n < chunk && R >= 19 && !pmx_env("PMX_STATS_NO_SHORT_TAIL")) {
+        if (short_waves && R >= 19 && !pmx_env("PMX_STATS_NO_SHORT_TAIL")) {
             int v2 = 0, T2 = 0, G2 = 0, R2 = 0; size_t tb2 = 0;
-            if (pmx_nwsgq_trace_plan(bk, dm.d, cfg->mode, cfg->open, cfg->extend, &v2, &T2, &tb2, &G2, &R2, 1) == 0 && tb2 <= cbytes) {
+            if (pmx_nwsgq_trace_plan(bk, dm.d, cfg->mode, cfg->open, cfg->extend, &v2, &T2, &tb2, &G2, &R2, 1) == 0 && tb2 <= tb_bytes) {
                 variant_k = v2; Tmax_k = T2; G_k = G2; R_k = R2;
             }
         }
@@ -1523,16 +1536,30 @@ static int stats_by_trace_shared(const pmx_config_t *cfg, const DevMat &dm, cons
         if (rc) { set_err("shared-profile traceback sweep failed (%d)", rc); return rc < 0 ? rc : -1; }
         hipStream_t ws = st;
         if (two) {
-            HIP_OR_RET(hipEventRecord(g_tws.sweep_done[idx & 1], sws));
-            HIP_OR_RET(hipStreamWaitEvent(g_tws.walk, g_tws.sweep_done[idx & 1], 0));
+            HIP_OR_RET(hipEventRecord(g_tws.sweep_done[slot], sws));
+            HIP_OR_RET(hipStreamWaitEvent(g_tws.walk, g_tws.sweep_done[slot], 0));
             ws = g_tws.walk;
         }
         rc = pmx_launch_walkp(gsel_k, R_k, bk, dm.d, cfg->mode, cfg->open, cfg->extend, Tmax_k, 0, st_k, row_pen, col_pen,
                               tb, out_k, nullptr, nullptr, 0, nullptr, nullptr, nullptr, ws);
         if (rc) { set_err("statistics walk failed (%d)", rc); return rc < 0 ? rc : -1; }
-        if (two) HIP_OR_RET(hipEventRecord(g_tws.walk_done[idx & 1], ws));
+        if (two) HIP_OR_RET(hipEventRecord(g_tws.walk_done[slot], ws));
+        return 0;
+    };
+    if (rem_n) {
+        const int rc = run_chunk(b.n - rem_n, rem_n, (uint32_t *)((unsigned char *)tbuf + 2 * cbytes), rbytes, g_tws.aux2, 2, true);
+        if (rc) return rc;
     }
-    if (two) HIP_OR_RET(hipStreamWaitEvent(st, g_tws.walk_done[(idx - 1) & 1], 0));
+    int idx = 0;
+    for (long long c0 = 0; c0 < b.n - rem_n; c0 += chunk, ++idx) {
+        const long long n_k = (b.n - rem_n - c0 < chunk) ? b.n - rem_n - c0 : chunk;
+        uint32_t *tb = (uint32_t *)((unsigned char *)tbuf + (two ? (size_t)(idx & 1) * cbytes : 0));
+        const hipStream_t sws = (two && (idx & 1)) ? g_tws.aux : st;
+        if (two && idx >= 2) HIP_OR_RET(hipStreamWaitEvent(sws, g_tws.walk_done[idx & 1], 0));    // this buffer's previous walk is done
+        const int rc = run_chunk(c0, n_k, tb, cbytes, sws, idx & 1, by_rounds && two && n_k < chunk);
+        if (rc) return rc;
+    }
+    if (two) HIP_OR_RET(hipStreamWaitEvent(st, g_tws.walk_done[(idx - 1) & 1], 0));      // (the walk stream is in order: the last walk covers all, the remainder's too)
     static thread_local char name[96];
     snprintf(name, sizeof name, "pmx_nwsg16q_kernel<%d,%d>/shared profile/packed trace + pmx_walkp_kernel/stats", G, R);
     g_last_kernel = name;

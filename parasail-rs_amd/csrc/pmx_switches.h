@@ -41,6 +41,7 @@ struct PmxSwitchDoc { const char *name, *kind, *what; };
     X("PMX_NWSGQ_NO_R20",             "force", "statistics by traceback, profile arm: the <32,10> shape instead of <16,20> for queries of 256-319 rows") \
     X("PMX_STATS_CHUNK_BYTES",        "value", "statistics by traceback: bytes of trace scratch per chunk (tests force several chunks)") \
     X("PMX_STATS_EQUAL_CHUNKS",       "force", "statistics by traceback, shared profile: chunks of equal size instead of whole rounds of resident workgroups") \
+    X("PMX_STATS_TAIL_LAST",          "force", "statistics by traceback, profile arm: the remainder after the whole rounds runs last on the shared trace buffers instead of first on a buffer of its own") \
     X("PMX_STATS_NO_SHORT_TAIL",      "force", "statistics by traceback, shared profile: the remainder chunk on the same shape as the whole rounds (not the half-length waves of <32,10>)") \
     X("PMX_STATS_NO_OVERLAP",         "force", "statistics by traceback: sweep and walk of every chunk back to back on one stream (no double buffering)") \
     X("PMX_NO_FAST_TRACE",            "force", "traceback: general kernel (1 byte per cell) instead of the packed 4-bit kernels") \

@@ -219,5 +219,5 @@ def test_every_switch_is_result_neutral(pkg, orc, monkeypatch):
     # a switch that reroutes nothing here would be tested in name only (chunk sizes and variant caps change no kernel name)
     same_name = set(VALUES) | {"PMX_CIGAR_NO_OVERLAP", "PMX_STATS_NO_OVERLAP", "PMX_TRACE_NO_BFI", "PMX_TRACE_FETCH",      # another instance / schedule of one kernel
                                "PMX_BSTRIP_TIES_INLINE", "PMX_BSTRIP_CELL_GUARDS", "PMX_DEFER_ALIGN", "PMX_LONG_TWO_COLUMNS", "PMX_LONG_ONE_COLUMN",
-                               "PMX_NO_FAST_TABLE", "PMX_GENERAL_ONE_WAVE", "PMX_NWSGQ_ENDS_ALWAYS", "PMX_STATS_EQUAL_CHUNKS", "PMX_STATS_NO_SHORT_TAIL"}                       # (single calls do not record a name)
+                               "PMX_NO_FAST_TABLE", "PMX_GENERAL_ONE_WAVE", "PMX_NWSGQ_ENDS_ALWAYS", "PMX_STATS_EQUAL_CHUNKS", "PMX_STATS_NO_SHORT_TAIL", "PMX_STATS_TAIL_LAST"}                       # (single calls do not record a name)
     assert all(any(k in same_name for k in env) for env in inert), inert
