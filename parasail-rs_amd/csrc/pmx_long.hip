@@ -52,7 +52,9 @@ struct PmxLongArgs {
 };
 
 __device__ __forceinline__ int dpp_wave_shr(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, 0x138 /*wave_shr:1*/, 0xF, 0xF, false); }
-__device__ __forceinline__ int dpp_wave_shl(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x130 /*wave_shl:1*/, 0xF, 0xF, false); }
+// (lane 63 has no source and gets 0: what enters there reaches lane 0 only after 64 shifts, and every rotating register is reloaded by then;
+//  without an `old` operand the result is not tied to the source's register -- one v_mov_b32 less per shift)
+__device__ __forceinline__ int dpp_wave_shl(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130 /*wave_shl:1*/, 0xF, 0xF, true); }
 
 template <int R, int MODE, int CH /* columns per boundary chunk: 64, or 16 (lanes 0 .. 15 load; a band runs ~50 steps closer behind the one above) */>
 __global__ __launch_bounds__(64)
@@ -166,9 +168,11 @@ void pmx_long32_kernel(PmxLongArgs a)
     };
 
     // one step; EDGE: lanes whose column t - g is outside [0, rl) exist (fill / drain), and the last column is captured
-    auto step = [&](const int (&Hold)[R], int (&Hnew)[R], const int (&w)[R / 2], int (&wn)[R / 2], int t, auto edge) {
+    auto step = [&](const int (&Hold)[R], int (&Hnew)[R], const int (&w)[R / 2], int (&wn)[R / 2], int t, auto edge, auto last_of_chunk) {
         constexpr bool EDGE = decltype(edge)::value;
-        if (((t + 1) & 63) == 0) reload_sym(t + 1);
+        // (a new 64-column chunk of symbols can only begin behind the LAST step of a boundary chunk: the other steps do not test for it --
+        //  a wave alone on its SIMD issues one instruction of any kind per 4 cycles, so the two scalar instructions of the test count)
+        if (decltype(last_of_chunk)::value && ((t + 1) & 63) == 0) reload_sym(t + 1);
         advance(wn);                                       // the next step's scores, in flight while this step computes
         __builtin_amdgcn_sched_barrier(0);
         const int Hin = dpp_wave_shr(Hb, Hout), Fin = dpp_wave_shr(Fb, Fout);
@@ -210,7 +214,7 @@ void pmx_long32_kernel(PmxLongArgs a)
                 }
             }
         }
-        if (bout && lane == 63 && t >= 63)
+        if (bout && lane == 63 && (!EDGE || t >= 63))
             __hip_atomic_store(bout + (t - 63), ((unsigned long long)(unsigned)Fout << 32) | (unsigned)Hout, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     };
@@ -223,15 +227,19 @@ void pmx_long32_kernel(PmxLongArgs a)
     for (int base = 0; base < T; base += CH) {          // (lanes CH .. 63 never hold the fill pattern: `ngran` starts at 0 there)
         reload_bound(base);
         if (base >= 64 && base < tB) {
-            for (int t = base; t < base + CH; t += 2) {
-                step(HA, HB, w0, w1, t, std::false_type());
-                step(HB, HA, w1, w0, t + 1, std::false_type());
+            for (int t = base; t < base + CH - 2; t += 2) {
+                step(HA, HB, w0, w1, t, std::false_type(), std::false_type());
+                step(HB, HA, w1, w0, t + 1, std::false_type(), std::false_type());
             }
+            step(HA, HB, w0, w1, base + CH - 2, std::false_type(), std::false_type());
+            step(HB, HA, w1, w0, base + CH - 1, std::false_type(), std::true_type());
         } else {
-            for (int t = base; t < base + CH; t += 2) {
-                step(HA, HB, w0, w1, t, std::true_type());
-                step(HB, HA, w1, w0, t + 1, std::true_type());
+            for (int t = base; t < base + CH - 2; t += 2) {
+                step(HA, HB, w0, w1, t, std::true_type(), std::false_type());
+                step(HB, HA, w1, w0, t + 1, std::true_type(), std::false_type());
             }
+            step(HA, HB, w0, w1, base + CH - 2, std::true_type(), std::false_type());
+            step(HB, HA, w1, w0, base + CH - 1, std::true_type(), std::true_type());
         }
     }
 
@@ -388,9 +396,9 @@ void pmx_long32_kernel_c2(PmxLongArgs a)
         else { const int2 va = *reinterpret_cast<const int2 *>(pa), vb = *reinterpret_cast<const int2 *>(pb); wa[0] = va.x; wa[1] = va.y; wb[0] = vb.x; wb[1] = vb.y; }
     };
 
-    auto step = [&](const int (&wa)[R / 2], const int (&wb)[R / 2], int (&na)[R / 2], int (&nb)[R / 2], int t, auto edge) {
+    auto step = [&](const int (&wa)[R / 2], const int (&wb)[R / 2], int (&na)[R / 2], int (&nb)[R / 2], int t, auto edge, auto last_of_chunk) {
         constexpr bool EDGE = decltype(edge)::value;
-        if (((t + 1) & 63) == 0) reload_sym(t + 1);
+        if (decltype(last_of_chunk)::value && ((t + 1) & 63) == 0) reload_sym(t + 1);
         advance(na, nb);
         __builtin_amdgcn_sched_barrier(0);
         const int Hin0 = dpp_wave_shr(Hb0, Hout0), Fin0 = dpp_wave_shr(Fb0, Fout0);
@@ -460,7 +468,7 @@ void pmx_long32_kernel_c2(PmxLongArgs a)
                 }
             }
         }
-        if (bout && lane == 63 && t >= 63) {
+        if (bout && lane == 63 && (!EDGE || t >= 63)) {
             __hip_atomic_store(bout + 2 * (t - 63), ((unsigned long long)(unsigned)Fout0 << 32) | (unsigned)Hout0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(bout + 2 * (t - 63) + 1, ((unsigned long long)(unsigned)Fout1 << 32) | (unsigned)Hout1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -473,15 +481,19 @@ void pmx_long32_kernel_c2(PmxLongArgs a)
     for (int base = 0; base < T; base += CH) {
         reload_bound(base);
         if (base >= 64 && 2 * (base + CH) < rl) {          // every lane's two columns are inside the reference and left of its last column
-            for (int t = base; t < base + CH; t += 2) {
-                step(wa0, wb0, wa1, wb1, t, std::false_type());
-                step(wa1, wb1, wa0, wb0, t + 1, std::false_type());
+            for (int t = base; t < base + CH - 2; t += 2) {
+                step(wa0, wb0, wa1, wb1, t, std::false_type(), std::false_type());
+                step(wa1, wb1, wa0, wb0, t + 1, std::false_type(), std::false_type());
             }
+            step(wa0, wb0, wa1, wb1, base + CH - 2, std::false_type(), std::false_type());
+            step(wa1, wb1, wa0, wb0, base + CH - 1, std::false_type(), std::true_type());
         } else {
-            for (int t = base; t < base + CH; t += 2) {
-                step(wa0, wb0, wa1, wb1, t, std::true_type());
-                step(wa1, wb1, wa0, wb0, t + 1, std::true_type());
+            for (int t = base; t < base + CH - 2; t += 2) {
+                step(wa0, wb0, wa1, wb1, t, std::true_type(), std::false_type());
+                step(wa1, wb1, wa0, wb0, t + 1, std::true_type(), std::false_type());
             }
+            step(wa0, wb0, wa1, wb1, base + CH - 2, std::true_type(), std::false_type());
+            step(wa1, wb1, wa0, wb0, base + CH - 1, std::true_type(), std::true_type());
         }
     }
 
