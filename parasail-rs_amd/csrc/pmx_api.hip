@@ -1594,9 +1594,11 @@ static int long_batch(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch 
     if (n <= 16) {
         const bool sw = cfg->mode == PMX_MODE_SW;
         const double nb4 = (max_qlen + 255) / 256, nb2 = (max_qlen + 127) / 128, cols = max_rlen;
-        const double t1 = cols * (sw ? 144 : 117) + nb4 * (sw ? 23500 : 22400);
-        const double t24 = cols * (sw ? 113 : 100) + nb4 * (sw ? 35600 : 26400);
-        const double t22 = cols * (sw ? 91 : 76) + nb2 * (sw ? 25300 : 19800);
+        // (ns per column and ns per band, measured at the end of round 4: local alignment in the plain form, global / semi-global in the
+        //  form with column skew and row offset -- profiles/r04/long_shapes.txt, long_single_forms.txt)
+        const double t1 = cols * (sw ? 156 : 115) + nb4 * (sw ? 18400 : 15700);
+        const double t24 = cols * (sw ? 111 : 78.6) + nb4 * (sw ? 32600 : 20100);
+        const double t22 = cols * (sw ? 85 : 62.4) + nb2 * (sw ? 23100 : 16400);
         if (t22 < 0.95 * t1 && t22 <= t24) { two_cols = 1; R = 2; }          // (within 5 %: the first form)
         else if (t24 < 0.95 * t1) two_cols = 1;
     }
@@ -1633,9 +1635,14 @@ static int long_batch(const pmx_config_t *cfg, const DevMat &dm, const PmxBatch 
         if (rc) return c0 == 0 ? 1 : (set_err("long-pair kernel refused a later chunk"), -1);
     }
     // did a band give up waiting?  (The one host synchronisation of this path; one-pair calls synchronise right after anyway.)
-    int gave_up = 0;
-    HIP_OR_RET(hipMemcpyAsync(&gave_up, scr, sizeof(int), hipMemcpyDeviceToHost, st));
+    // (into pinned memory: an asynchronous copy to pageable memory goes through the runtime's staging thread, and the synchronisation
+    //  behind it was seen to take 20-30 ms in steps of 10 ms for a 5 ms batch)
+    static thread_local int *pin_flag = nullptr;
+    if (!pin_flag) HIP_OR_RET(hipHostMalloc((void **)&pin_flag, 64, hipHostMallocDefault));
+    *pin_flag = 0;
+    HIP_OR_RET(hipMemcpyAsync(pin_flag, scr, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_OR_RET(hipStreamSynchronize(st));
+    const int gave_up = *pin_flag;
     if (gave_up) {
         set_err("long-pair kernel: a band's bounded wait for the band above ran out (dispatch order assumption broken, or PMX_LONG_SPIN_LIMIT); "
                 "the call was redone on the per-pair kernels");

@@ -62,6 +62,11 @@ void pmx_long32_kernel(PmxLongArgs a)
 {
     constexpr int BR = 64 * R;
     constexpr bool SW = MODE == PMX_MODE_SW, SG = MODE == PMX_MODE_SG;
+    // SKEW (global / semi-global, round 4): every value of cell (i, j) is kept + (i + j) * ext, so neither gap needs its subtraction:
+    // E(j) = max(E(j - 1), X(j - 1)), F(i) = max(F(i - 1), X(i - 1)) with X = H - (open - ext); the diagonal step crosses a row and a
+    // column: + 2 ext, folded into the profile (score + open + ext).  5 instructions per cell instead of 7; boundaries and granules are in
+    // the same form (the offset is global), captures take it off.  Local alignment keeps the plain form: its zero floor is per cell.
+    constexpr bool SKEW = !SW;
     const int lane = threadIdx.x;
     const long long pair = blockIdx.x / a.nbmax;
     const int band = (int)(blockIdx.x % a.nbmax);
@@ -83,7 +88,7 @@ void pmx_long32_kernel(PmxLongArgs a)
     for (int row = lane; row < BR; row += 64) {                        // the profile carries score + open (the strips carry H - open)
         const int i = band * BR + row;
         const int qs = i < ql ? (int)map[q[i]] : -1;
-        for (int sym = 0; sym < msize; ++sym) prof[sym * BR + row] = (int16_t)(qs < 0 ? LONG_PAD : mat[qs * msize + sym] + open);
+        for (int sym = 0; sym < msize; ++sym) prof[sym * BR + row] = (int16_t)(qs < 0 ? LONG_PAD : mat[qs * msize + sym] + open + (SKEW ? ext : 0));
         prof[msize * BR + row] = (int16_t)LONG_PAD;
     }
     __syncthreads();
@@ -96,8 +101,8 @@ void pmx_long32_kernel(PmxLongArgs a)
     const int i0 = band * BR + lane * R;
     int HA[R], HB[R], E[R], hs[R], lc[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) { HA[k] = left(i0 + k) - open; HB[k] = HA[k]; E[k] = LONG_NEG; hs[k] = 0; lc[k] = LONG_NEG; }
-    int diag = left(i0 - 1) - open;
+    for (int k = 0; k < R; ++k) { HA[k] = left(i0 + k) - open + (SKEW ? (i0 + k) * ext : 0); HB[k] = HA[k]; E[k] = LONG_NEG; hs[k] = 0; lc[k] = LONG_NEG; }
+    int diag = left(i0 - 1) - open + (SKEW ? (i0 - 1) * ext : 0);
     int Hout = 0, Fout = 0;
     int best = SW ? -open - 1 : 0, bcol = 0;
     // sg, reference end free: the lane and register that hold the query's last row (last band only)
@@ -145,7 +150,7 @@ void pmx_long32_kernel(PmxLongArgs a)
         } else if (bin) {
             Hb = 0; Fb = 0;
         } else {
-            Hb = top(base + lane) - open;                  // H(-1, j) - open; F(0, j) = max(-inf, H(-1, j) - open)
+            Hb = top(base + lane) - open + (SKEW ? (base + lane) * ext : 0);      // H(-1, j) - open; F(0, j) = max(-inf, H(-1, j) - open)
             Fb = SW ? 0 : Hb;
         }
         if (base + CH < T) prefetch_bound(base + CH);
@@ -183,11 +188,11 @@ void pmx_long32_kernel(PmxLongArgs a)
             for (int k = 0; k < R; ++k) {
                 const int s = (k & 1) ? (w[k / 2] >> 16) : (int)(short)(w[k / 2] & 0xFFFF);
                 const int Tt = d + s;
-                const int En = max(E[k] - ext, Hold[k]);
+                const int En = SKEW ? max(E[k], Hold[k]) : max(E[k] - ext, Hold[k]);
                 int H = max(max(Tt, En), F);
-                const int Ho = H - open;
+                const int Ho = H - (SKEW ? open - ext : open);
                 E[k] = En;
-                F = SW ? max(max(F - ext, Ho), 0) : max(F - ext, Ho);
+                F = SW ? max(max(F - ext, Ho), 0) : SKEW ? max(F, Ho) : max(F - ext, Ho);
                 d = Hold[k];
                 Hnew[k] = Ho;
             }
@@ -210,6 +215,7 @@ void pmx_long32_kernel(PmxLongArgs a)
                     int hr = Hnew[0];
 #pragma unroll
                     for (int k = 1; k < R; ++k) hr = (kstar == k) ? Hnew[k] : hr;
+                    if (SKEW) hr -= (t - lane) * ext;      // (one row, many columns: the column part of the offset comes off)
                     if (lane == gstar && (!EDGE || t - lane < rl) && hr > rbest) { rbest = hr; rcol = t - lane; }
                 }
             }
@@ -262,7 +268,10 @@ void pmx_long32_kernel(PmxLongArgs a)
         // last column: this band's best over its rows, smallest row first
         int sc = LONG_NEG, row = 0x7FFFFFFF;
 #pragma unroll
-        for (int k = R - 1; k >= 0; --k) if (i0 + k < ql && lc[k] + open >= sc) { sc = lc[k] + open; row = i0 + k; }
+        for (int k = R - 1; k >= 0; --k) {
+            const int v = lc[k] + open - (SKEW ? ext + (i0 + k + rl - 1) * ext : 0);      // (the offset of cell (i0 + k, rl - 1) comes off)
+            if (i0 + k < ql && v >= sc) { sc = v; row = i0 + k; }
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             const int os = __shfl_xor(sc, off, 64), orow = __shfl_xor(row, off, 64);
@@ -274,8 +283,8 @@ void pmx_long32_kernel(PmxLongArgs a)
             int corner = lc[0];
 #pragma unroll
             for (int k = 1; k < R; ++k) corner = (kstar == k) ? lc[k] : corner;
-            cand[7] = corner + open;
-            cand[5] = rbest + open; cand[6] = rcol;
+            cand[7] = corner + open - (SKEW ? ext + (ql - 1 + rl - 1) * ext : 0);
+            cand[5] = rbest + open - (SKEW ? ext + (ql - 1) * ext : 0); cand[6] = rcol;
         }
     }
 }
@@ -294,6 +303,11 @@ void pmx_long32_kernel_c2(PmxLongArgs a)
 {
     constexpr int BR = 64 * R;
     constexpr bool SW = MODE == PMX_MODE_SW, SG = MODE == PMX_MODE_SG;
+    // SKEW (global / semi-global, round 4): every value of cell (i, j) is kept + (i + j) * ext, so neither gap needs its subtraction:
+    // E(j) = max(E(j - 1), X(j - 1)), F(i) = max(F(i - 1), X(i - 1)) with X = H - (open - ext); the diagonal step crosses a row and a
+    // column: + 2 ext, folded into the profile (score + open + ext).  5 instructions per cell instead of 7; boundaries and granules are in
+    // the same form (the offset is global), captures take it off.  Local alignment keeps the plain form: its zero floor is per cell.
+    constexpr bool SKEW = !SW;
     const int lane = threadIdx.x;
     const long long pair = blockIdx.x / a.nbmax;
     const int band = (int)(blockIdx.x % a.nbmax);
@@ -315,7 +329,7 @@ void pmx_long32_kernel_c2(PmxLongArgs a)
     for (int row = lane; row < BR; row += 64) {                        // the profile carries score + open (the strips carry H - open)
         const int i = band * BR + row;
         const int qs = i < ql ? (int)map[q[i]] : -1;
-        for (int sym = 0; sym < msize; ++sym) prof[sym * BR + row] = (int16_t)(qs < 0 ? LONG_PAD : mat[qs * msize + sym] + open);
+        for (int sym = 0; sym < msize; ++sym) prof[sym * BR + row] = (int16_t)(qs < 0 ? LONG_PAD : mat[qs * msize + sym] + open + (SKEW ? ext : 0));
         prof[msize * BR + row] = (int16_t)LONG_PAD;
     }
     __syncthreads();
@@ -328,8 +342,8 @@ void pmx_long32_kernel_c2(PmxLongArgs a)
     const int i0 = band * BR + lane * R;
     int H[R], E[R], hs[R], lc[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) { H[k] = left(i0 + k) - open; E[k] = LONG_NEG; hs[k] = 0; lc[k] = LONG_NEG; }
-    int diag = left(i0 - 1) - open;
+    for (int k = 0; k < R; ++k) { H[k] = left(i0 + k) - open + (SKEW ? (i0 + k) * ext : 0); E[k] = LONG_NEG; hs[k] = 0; lc[k] = LONG_NEG; }
+    int diag = left(i0 - 1) - open + (SKEW ? (i0 - 1) * ext : 0);
     int Hout0 = 0, Hout1 = 0, Fout0 = 0, Fout1 = 0;
     int best = SW ? -open - 1 : 0, bcol = 0;
     const int gstar = ((ql - 1) % BR) / R, kstar = (ql - 1) % R;
@@ -382,7 +396,7 @@ void pmx_long32_kernel_c2(PmxLongArgs a)
         } else if (bin) {
             Hb0 = 0; Fb0 = 0; Hb1 = 0; Fb1 = 0;
         } else {
-            Hb0 = top(2 * (base + lane)) - open; Hb1 = top(2 * (base + lane) + 1) - open;
+            Hb0 = top(2 * (base + lane)) - open + (SKEW ? 2 * (base + lane) * ext : 0); Hb1 = top(2 * (base + lane) + 1) - open + (SKEW ? (2 * (base + lane) + 1) * ext : 0);
             Fb0 = SW ? 0 : Hb0; Fb1 = SW ? 0 : Hb1;
         }
         if (base + CH < T) prefetch_bound(base + CH);
@@ -412,22 +426,22 @@ void pmx_long32_kernel_c2(PmxLongArgs a)
                 {   // column 2 (t - g), row k
                     const int s = (k & 1) ? (wa[k / 2] >> 16) : (int)(short)(wa[k / 2] & 0xFFFF);
                     const int Tt = d0 + s;
-                    const int En = max(E[k] - ext, H[k]);
+                    const int En = SKEW ? max(E[k], H[k]) : max(E[k] - ext, H[k]);
                     const int Hh = max(max(Tt, En), F0);
-                    const int Ho = Hh - open;
+                    const int Ho = Hh - (SKEW ? open - ext : open);
                     E[k] = En;
-                    F0 = SW ? max(max(F0 - ext, Ho), 0) : max(F0 - ext, Ho);
+                    F0 = SW ? max(max(F0 - ext, Ho), 0) : SKEW ? max(F0, Ho) : max(F0 - ext, Ho);
                     d0 = H[k];
                     N0[k] = Ho;
                 }
                 {   // column 2 (t - g) + 1, row k
                     const int s = (k & 1) ? (wb[k / 2] >> 16) : (int)(short)(wb[k / 2] & 0xFFFF);
                     const int Tt = d1 + s;
-                    const int En = max(E[k] - ext, N0[k]);
+                    const int En = SKEW ? max(E[k], N0[k]) : max(E[k] - ext, N0[k]);
                     const int Hh = max(max(Tt, En), F1);
-                    const int Ho = Hh - open;
+                    const int Ho = Hh - (SKEW ? open - ext : open);
                     E[k] = En;
-                    F1 = SW ? max(max(F1 - ext, Ho), 0) : max(F1 - ext, Ho);
+                    F1 = SW ? max(max(F1 - ext, Ho), 0) : SKEW ? max(F1, Ho) : max(F1 - ext, Ho);
                     d1 = N0[k];
                     N1[k] = Ho;
                 }
@@ -461,6 +475,7 @@ void pmx_long32_kernel_c2(PmxLongArgs a)
                     int h0 = N0[0], h1 = N1[0];
 #pragma unroll
                     for (int k = 1; k < R; ++k) { h0 = (kstar == k) ? N0[k] : h0; h1 = (kstar == k) ? N1[k] : h1; }
+                    if (SKEW) { h0 -= j0 * ext; h1 -= (j0 + 1) * ext; }      // (one row, many columns: the column part of the offset comes off)
                     if (lane == gstar) {
                         if ((!EDGE || j0 < rl) && h0 > rbest) { rbest = h0; rcol = j0; }
                         if ((!EDGE || j0 + 1 < rl) && h1 > rbest) { rbest = h1; rcol = j0 + 1; }
@@ -515,7 +530,10 @@ void pmx_long32_kernel_c2(PmxLongArgs a)
     } else {
         int sc = LONG_NEG, row = 0x7FFFFFFF;
 #pragma unroll
-        for (int k = R - 1; k >= 0; --k) if (i0 + k < ql && lc[k] + open >= sc) { sc = lc[k] + open; row = i0 + k; }
+        for (int k = R - 1; k >= 0; --k) {
+            const int v = lc[k] + open - (SKEW ? ext + (i0 + k + rl - 1) * ext : 0);      // (the offset of cell (i0 + k, rl - 1) comes off)
+            if (i0 + k < ql && v >= sc) { sc = v; row = i0 + k; }
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             const int os = __shfl_xor(sc, off, 64), orow = __shfl_xor(row, off, 64);
@@ -527,8 +545,8 @@ void pmx_long32_kernel_c2(PmxLongArgs a)
             int corner = lc[0];
 #pragma unroll
             for (int k = 1; k < R; ++k) corner = (kstar == k) ? lc[k] : corner;
-            cand[7] = corner + open;
-            cand[5] = rbest + open; cand[6] = rcol;
+            cand[7] = corner + open - (SKEW ? ext + (ql - 1 + rl - 1) * ext : 0);
+            cand[5] = rbest + open - (SKEW ? ext + (ql - 1) * ext : 0); cand[6] = rcol;
         }
     }
 }
@@ -589,7 +607,7 @@ int pmx_launch_long(const PmxBatch &b, const PmxDevMatrix &m, int mode, int sg_f
                     void *scratch, pmx_record_t *d_out, int sat_above, int force_sat, hipStream_t stream, int spin_limit, int chunk_cols, int two_cols)
 {
     if (b.perm || m.msize > 64) return 1;
-    if (m.max + open > 32000 || m.min + open < -16000 || open < 0 || ext < 0) return 1;      // int16 profile entries
+    if (m.max + open + ext > 32000 || m.min + open < -16000 || open < 0 || ext < 0) return 1;      // int16 profile entries (score + open [+ ext])
     if ((long long)(b.max_qlen + b.max_rlen) * (long long)(ext > open ? ext : open) > (1LL << 29)) return 1;   // boundary values stay above LONG_NEG
     PmxLongArgs a;
     a.qbuf = b.qbuf; a.qoff = b.qoff; a.q_shared = b.q_shared; a.rbuf = b.rbuf; a.roff = b.roff; a.n = b.n;
