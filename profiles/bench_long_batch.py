@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""A batch of long pairs (512 x 5 kbp x 5 kbp, queries beyond the packed kernels' 2 048 rows) through the long-pair kernel, per form."""
+"""A batch of long pairs (512 x 5 kbp x 5 kbp, queries beyond the packed kernels' 2 048 rows) through the long-pair kernel, per form.
+Wall time of the host entry (host buffers in, records out).  On a shared GPU host the runtime's synchronisation behind such a 4 ms batch
+was seen to take 20-30 ms in steps of 10 ms in some processes (the first process of a session never): trust the fastest run -- the
+kernels under rocprofv3 take 3.5 ms (global, skewed form) and 5.2 ms (local) whatever the wall clock says."""
 import os, sys, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
